@@ -1,0 +1,1081 @@
+// radtran_api.hip -- host side of the C ABI declared in include/clima_radtran_hip.h.
+//
+// Mirrors `type Radtran` (src/radtran/clima_radtran.f90:31-85): the handle owns the
+// tables and work arrays in HBM, a HIP stream, and host mirrors of the small results.
+// There is no CPU fallback anywhere in this file: if HIP is unavailable every compute
+// entry point reports the HIP error in `err`.
+#include "../../include/clima_radtran_hip.h"
+#include "radtran_dev.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace clima;
+
+namespace {
+
+constexpr unsigned MAGIC = 0xC11AAD17u;
+
+void set_err(char *err, const std::string &msg) {
+  if (!err) return;
+  std::strncpy(err, msg.c_str(), CLIMA_ERR_LEN);
+  err[CLIMA_ERR_LEN] = 0;
+}
+void clear_err(char *err) {
+  if (err) err[0] = 0;
+}
+
+struct HipFail {
+  std::string msg;
+};
+#define HIPCHK(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      throw HipFail{std::string("HIP error in " #call ": ") + hipGetErrorString(e_)};        \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+  }
+  void upload(const std::vector<T> &v) {
+    alloc(v.size());
+    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void zero(hipStream_t s = nullptr) {
+    if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+struct KTabHost {
+  int sp, ng, nP, nT;
+  std::vector<double> weights, log10P, temp, log10k;
+  DevBuf<double> d_log10k, d_log10P, d_temp;
+};
+struct XsHost {
+  int type, dim, sp1, sp2, nT;
+  std::vector<double> temp, data;
+  DevBuf<double> d_data, d_temp;
+};
+struct PartHost {
+  int p_ind, nrad;
+  std::vector<double> radii, w0, qext, gt;
+  DevBuf<double> d_radii, d_w0, d_qext, d_gt;
+};
+
+struct Radtran;
+struct ChannelObj {  // RTChannel, clima_radtran_types.f90:263-269
+  Radtran *parent = nullptr;
+  int which = 0;
+  int ind_start = 0, ind_end = -1, nw = 0;  // 0-based, inclusive end
+  std::vector<double> wavl, freq;
+  DevBuf<double> d_freq;
+};
+struct WrkObj {  // ClimaRadtranWrk, clima_radtran.f90:11-25
+  Radtran *parent = nullptr;
+  int which = 0;
+  DevBuf<double> fup_a, fdn_a, amean, tau_band;
+};
+
+struct Radtran {
+  unsigned magic = MAGIC;
+  int state = 0;  // 0 allocated, 1 begun, 2 finalized
+  int nz = 0, nsp = 0, np = 0, nw = 0, ng = 0;
+  std::vector<double> wavl, freq;
+  std::vector<KTabHost *> k;
+  std::vector<XsHost *> cia, ray, pxs;
+  std::vector<PartHost *> part;
+  bool has_cont = false;
+  int LH2O = -1, cont_nT = 0;
+  std::vector<double> cont_temp, cont_H2O, cont_foreign;
+  DevBuf<double> d_cont_temp, d_cont_H2O, d_cont_foreign;
+  std::vector<double> wbin, wbin_e, wxy;
+  DevBuf<double> d_wbin, d_wbin_e, d_wxy, d_freq;
+  ChannelObj ir, sol;
+  WrkObj wrk_ir, wrk_sol;
+  // public fields (clima_radtran.f90:51-68)
+  double diurnal_fac = 0.5;
+  std::vector<double> zenith_u, zenith_w, surface_albedo, surface_emissivity, photons_sol;
+  bool has_hard_surface = true;
+  double ir_tau_min = 1.0e-6;
+  double photon_scale_factor = 1.0;
+  bool fields_dirty = true;
+  DevBuf<double> d_zen_u, d_zen_w, d_albedo, d_emis, d_photons, d_am_f1, d_am_f2, d_am_dw;
+  // column + prep
+  int nslots = 0;
+  std::vector<SlotDev> slots;
+  DevBuf<double> d_col;  // [T_surface | T | P | dz | dens | pdens | radii]
+  DevBuf<double> d_log10P, d_cols, d_foreign, d_q;
+  DevBuf<int> d_src, d_ix, d_err;
+  double *h_col = nullptr;  // pinned staging
+  size_t col_count = 0;
+  bool column_has_particles = false;
+  bool column_loaded = false;
+  std::vector<double> last_T, last_P, last_radii;  // host copy for byte accounting
+  // opr
+  DevBuf<double> d_tau, d_w0, d_g, d_tau_band;
+  bool opr_valid = false;
+  // results
+  DevBuf<double> d_flux_n, d_f_total;
+  double *h_small = nullptr;  // pinned: flux_n[4*(nz+1)] | f_total[nz+1] | err flag (as double slot)
+  int *h_errflag = nullptr;
+  std::vector<double> f_total;
+  bool small_valid = false;
+  // sharding
+  int shard_rank = 0, shard_world = 1;
+  int op_lo = 0, op_n = 0, ir_lo = 0, ir_n = 0, sol_lo = 0, sol_n = 0;
+  // stream + profiling
+  hipStream_t stream = nullptr;
+  bool profile = false;
+  struct Ev { hipEvent_t a, b; int id; };
+  std::vector<Ev> pending;
+  std::vector<hipEvent_t> pool;
+  double k_ms[4] = {0, 0, 0, 0};
+  int k_n[4] = {0, 0, 0, 0};
+  size_t ts_lds = 0;
+
+  ~Radtran() {
+    for (auto *x : k) delete x;
+    for (auto *x : cia) delete x;
+    for (auto *x : ray) delete x;
+    for (auto *x : pxs) delete x;
+    for (auto *x : part) delete x;
+    for (auto &e : pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : pool) (void)hipEventDestroy(e);
+    if (h_col) (void)hipHostFree(h_col);
+    if (h_small) (void)hipHostFree(h_small);
+    if (h_errflag) (void)hipHostFree(h_errflag);
+    if (stream) (void)hipStreamDestroy(stream);
+    magic = 0;
+  }
+};
+
+Radtran *as_rad(void *ptr) {
+  Radtran *r = reinterpret_cast<Radtran *>(ptr);
+  if (!r || r->magic != MAGIC) return nullptr;
+  return r;
+}
+
+// futils is_close (fortran-stdlib form)
+bool is_close(double a, double b, double tol) { return std::fabs(a - b) <= std::fabs(tol * std::max(std::fabs(a), std::fabs(b))); }
+
+// futils gauss_legendre (setup only, clima_eqns.f90:26-41)
+void gauss_legendre(int n, std::vector<double> &x, std::vector<double> &w) {
+  x.assign(n, 0.0);
+  w.assign(n, 0.0);
+  for (int i = 0; i < n; i++) {
+    double z = std::cos(PI * (i + 0.75) / (n + 0.5)), pp = 0.0;
+    for (int it = 0; it < 100; it++) {
+      double p1 = 1.0, p2 = 0.0;
+      for (int j = 0; j < n; j++) {
+        double p3 = p2;
+        p2 = p1;
+        p1 = ((2.0 * j + 1.0) * z * p2 - j * p3) / (j + 1.0);
+      }
+      pp = n * (z * p1 - p2) / (z * z - 1.0);
+      double z1 = z;
+      z = z1 - p1 / pp;
+      if (std::fabs(z - z1) < 1e-16) break;
+    }
+    x[n - 1 - i] = z;
+    w[n - 1 - i] = 2.0 / ((1.0 - z * z) * pp * pp);
+  }
+}
+
+int host_bracket(const std::vector<double> &xt, double x) {
+  int n = (int)xt.size();
+  if (x < xt[0]) return 0;
+  if (x >= xt[n - 1]) return n - 2;
+  int lo = 0, hi = n - 1;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) / 2;
+    if (x < xt[mid]) hi = mid; else lo = mid;
+  }
+  return lo;
+}
+
+// create_RTChannel, types_create.f90:226-270
+bool make_channel(Radtran *r, ChannelObj &c, int which, int n, const double *wavl, char *err) {
+  int ind1 = 0, ind2 = 0;
+  double best1 = INFINITY, best2 = INFINITY;
+  for (int i = 0; i < r->nw + 1; i++) {
+    double d1 = std::fabs(wavl[0] - r->wavl[i]), d2 = std::fabs(wavl[n - 1] - r->wavl[i]);
+    if (d1 < best1) { best1 = d1; ind1 = i; }
+    if (d2 < best2) { best2 = d2; ind2 = i; }
+  }
+  const char *msg = "The wavelength bins are not compatible with the k-distribution wavelength bins.";
+  if (n != ind2 - ind1 + 1) { set_err(err, msg); return false; }
+  for (int i = 0; i < n; i++)
+    if (!is_close(wavl[i], r->wavl[ind1 + i], 1.0e-7)) { set_err(err, msg); return false; }
+  c.parent = r;
+  c.which = which;
+  c.nw = n - 1;
+  c.wavl.assign(wavl, wavl + n);
+  c.freq.resize(n);
+  for (int i = 0; i < n; i++) c.freq[i] = C_LIGHT / (wavl[i] * 1.0e-9);
+  c.ind_start = ind1;
+  c.ind_end = ind2 - 1;
+  return true;
+}
+
+void upload_fields(Radtran *r) {
+  if (!r->fields_dirty) return;
+  r->d_zen_u.upload(r->zenith_u);
+  r->d_zen_w.upload(r->zenith_w);
+  r->d_albedo.upload(r->surface_albedo);
+  r->d_emis.upload(r->surface_emissivity);
+  r->d_photons.upload(r->photons_sol);
+  r->fields_dirty = false;
+}
+
+void compute_shard(Radtran *r) {
+  // contiguous opacity-bin ranges balanced by work: opacity 1, IR solve 1, solar solve
+  // 1 + nzen/2; rank 0-based.
+  const int nw = r->nw, W = r->shard_world, R = r->shard_rank;
+  std::vector<double> cost(nw + 1, 0.0);
+  const int nzen = (int)r->zenith_u.size();
+  for (int l = 0; l < nw; l++) {
+    double c = 1.0;
+    if (l >= r->ir.ind_start && l <= r->ir.ind_end) c += 1.0;
+    if (l >= r->sol.ind_start && l <= r->sol.ind_end) c += 1.0 + 0.5 * nzen;
+    cost[l + 1] = cost[l] + c;
+  }
+  auto cut = [&](int k) {
+    if (k <= 0) return 0;
+    if (k >= W) return nw;
+    double target = cost[nw] * k / W;
+    return (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
+  };
+  int lo = cut(R), hi = cut(R + 1);
+  if (W == 1) { lo = 0; hi = nw; }
+  r->op_lo = lo;
+  r->op_n = hi - lo;
+  auto clip = [&](const ChannelObj &c, int &clo, int &cn) {
+    int a = std::max(lo, c.ind_start), b = std::min(hi - 1, c.ind_end);
+    if (b < a) { clo = 0; cn = 0; } else { clo = a - c.ind_start; cn = b - a + 1; }
+  };
+  clip(r->ir, r->ir_lo, r->ir_n);
+  clip(r->sol, r->sol_lo, r->sol_n);
+}
+
+hipEvent_t get_event(Radtran *r) {
+  if (!r->pool.empty()) {
+    hipEvent_t e = r->pool.back();
+    r->pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIPCHK(hipEventCreate(&e));
+  return e;
+}
+
+struct KernelTimer {
+  Radtran *r;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  KernelTimer(Radtran *r_, int id_) : r(r_), id(id_) {
+    if (r->profile) {
+      a = get_event(r);
+      b = get_event(r);
+      HIPCHK(hipEventRecord(a, r->stream));
+    }
+  }
+  void stop() {
+    if (r->profile) {
+      HIPCHK(hipEventRecord(b, r->stream));
+      r->pending.push_back({a, b, id});
+    }
+  }
+};
+
+void resolve_events(Radtran *r) {
+  for (auto &e : r->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      r->k_ms[e.id] += ms;
+      r->k_n[e.id] += 1;
+    }
+    r->pool.push_back(e.a);
+    r->pool.push_back(e.b);
+  }
+  r->pending.clear();
+}
+
+ColumnDev column_dev(Radtran *r) {
+  ColumnDev c;
+  const int nz = r->nz;
+  double *base = r->d_col.p;
+  c.T_surface = base;
+  c.T = base + 1;
+  c.P = c.T + nz;
+  c.dz = c.P + nz;
+  c.dens = c.dz + nz;
+  c.pdens = c.dens + (size_t)r->nsp * nz;
+  c.radii = c.pdens + (size_t)r->np * nz;
+  c.log10P = r->d_log10P.p;
+  c.cols = r->d_cols.p;
+  c.foreign_col = r->d_foreign.p;
+  c.src = r->d_src.p;
+  c.ix = r->d_ix.p;
+  c.q = r->d_q.p;
+  c.err_flag = r->d_err.p;
+  return c;
+}
+
+void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
+  upload_fields(r);
+  const int nz = r->nz;
+  ColumnDev col = column_dev(r);
+  if (compute_opacity) {
+    HIPCHK(hipMemsetAsync(r->d_err.p, 0, sizeof(int), r->stream));
+    PrepParams pp;
+    std::memset(&pp, 0, sizeof(pp));
+    pp.nz = nz; pp.nsp = r->nsp; pp.np = r->np; pp.nslots = r->nslots;
+    pp.has_cont = r->has_cont; pp.LH2O = r->LH2O;
+    pp.check_radii = (r->column_has_particles && !r->part.empty()) ? 1 : 0;  // types.f90:628
+    for (int s = 0; s < r->nslots; s++) pp.slots[s] = r->slots[s];
+    pp.col = col;
+    { KernelTimer t(r, 0); launch_prep(pp, r->stream); t.stop(); }
+
+    OpacityParams op;
+    std::memset(&op, 0, sizeof(op));
+    op.nz = nz; op.nw = r->nw; op.ng = r->ng; op.nsp = r->nsp; op.np = r->np;
+    op.bin_lo = r->op_lo; op.nbins = r->op_n;
+    op.nk = (int)r->k.size(); op.ncia = (int)r->cia.size(); op.nray = (int)r->ray.size();
+    op.npxs = (int)r->pxs.size(); op.npart = (int)r->part.size();
+    op.has_cont = r->has_cont; op.LH2O = r->LH2O; op.cont_nT = r->cont_nT;
+    int slot = 0;
+    for (size_t i = 0; i < r->k.size(); i++) {
+      op.k[i] = KDev{r->k[i]->d_log10k.p, r->k[i]->sp, r->k[i]->nP, r->k[i]->nT, slot, slot + 1};
+      slot += 2;
+    }
+    auto fill = [&](std::vector<XsHost *> &v, XsDev *out) {
+      for (size_t i = 0; i < v.size(); i++) {
+        out[i] = XsDev{v[i]->d_data.p, v[i]->dim, v[i]->sp1, v[i]->sp2, v[i]->nT, v[i]->dim ? slot : -1};
+        if (v[i]->dim) slot++;
+      }
+    };
+    fill(r->cia, op.cia);
+    fill(r->pxs, op.pxs);
+    for (size_t i = 0; i < r->ray.size(); i++) op.ray[i] = XsDev{r->ray[i]->d_data.p, 0, r->ray[i]->sp1, -1, 0, -1};
+    if (r->has_cont) { op.cont_slot = slot++; op.cont_H2O = r->d_cont_H2O.p; op.cont_foreign = r->d_cont_foreign.p; }
+    for (size_t i = 0; i < r->part.size(); i++)
+      op.part[i] = PartDev{r->part[i]->d_w0.p, r->part[i]->d_qext.p, r->part[i]->d_gt.p, r->part[i]->p_ind, r->part[i]->nrad, slot++};
+    op.wbin = r->d_wbin.p; op.wbin_e = r->d_wbin_e.p; op.wxy = r->d_wxy.p;
+    op.col = col;
+    op.tau = r->d_tau.p; op.w0 = r->d_w0.p; op.g = r->d_g.p; op.tau_band = r->d_tau_band.p;
+    {
+      KernelTimer t(r, 1);
+      if (!launch_opacity(op, r->stream))
+        throw HipFail{"this build supports k-distributions with 8 g-points only (got " + std::to_string(r->ng) + ")"};
+      t.stop();
+    }
+    r->opr_valid = true;
+  }
+
+  TwoStreamParams ts;
+  std::memset(&ts, 0, sizeof(ts));
+  ts.nz = nz; ts.ng = r->ng;
+  ts.n_sol = compute_solar ? r->sol_n : 0; ts.sol_lo = r->sol_lo;
+  ts.n_ir = r->ir_n; ts.ir_lo = r->ir_lo;
+  ts.sol_start = r->sol.ind_start; ts.ir_start = r->ir.ind_start;
+  ts.tau = r->d_tau.p; ts.w0 = r->d_w0.p; ts.g = r->d_g.p; ts.tau_band = r->d_tau_band.p;
+  ts.wbin = r->d_wbin.p; ts.freq = r->d_freq.p;
+  ts.T = col.T; ts.T_surface = col.T_surface;
+  ts.emissivity = r->d_emis.p; ts.has_hard_surface = r->has_hard_surface ? 1 : 0; ts.ir_tau_min = r->ir_tau_min;
+  ts.nzen = (int)r->zenith_u.size(); ts.zen_u = r->d_zen_u.p; ts.zen_w = r->d_zen_w.p;
+  ts.albedo = r->d_albedo.p; ts.photons_sol = r->d_photons.p;
+  ts.photon_scale_factor = r->photon_scale_factor; ts.diurnal_fac = r->diurnal_fac;
+  ts.am_f1 = r->d_am_f1.p; ts.am_f2 = r->d_am_f2.p; ts.am_dw = r->d_am_dw.p;
+  ts.ir_fup_a = r->wrk_ir.fup_a.p; ts.ir_fdn_a = r->wrk_ir.fdn_a.p; ts.ir_tau_band = r->wrk_ir.tau_band.p;
+  ts.sol_fup_a = r->wrk_sol.fup_a.p; ts.sol_fdn_a = r->wrk_sol.fdn_a.p; ts.sol_amean = r->wrk_sol.amean.p;
+  ts.sol_tau_band = r->wrk_sol.tau_band.p;
+  {
+    KernelTimer t(r, 2);
+    if (!launch_twostream(ts, r->stream, &r->ts_lds))
+      throw HipFail{"nz*ngauss = " + std::to_string(nz * r->ng) + " exceeds what the two-stream kernel can stage in 160 KiB of LDS"};
+    t.stop();
+  }
+
+  IntegrateParams ip;
+  std::memset(&ip, 0, sizeof(ip));
+  ip.nz = nz; ip.nw_ir = r->ir.nw; ip.nw_sol = r->sol.nw;
+  ip.ir_lo = r->ir_lo; ip.ir_n = r->ir_n; ip.sol_lo = r->sol_lo; ip.sol_n = r->sol_n;
+  ip.do_solar = compute_solar ? 1 : 0;
+  ip.ir_fup_a = r->wrk_ir.fup_a.p; ip.ir_fdn_a = r->wrk_ir.fdn_a.p;
+  ip.sol_fup_a = r->wrk_sol.fup_a.p; ip.sol_fdn_a = r->wrk_sol.fdn_a.p;
+  ip.ir_freq = r->ir.d_freq.p; ip.sol_freq = r->sol.d_freq.p;
+  ip.flux_n = r->d_flux_n.p;
+  ip.f_total = r->shard_world == 1 ? r->d_f_total.p : nullptr;
+  { KernelTimer t(r, 3); launch_integrate(ip, r->stream); t.stop(); }
+  r->small_valid = false;
+}
+
+void fetch_small(Radtran *r) {
+  if (r->small_valid) return;
+  const int nl = r->nz + 1;
+  HIPCHK(hipMemcpyAsync(r->h_small, r->d_flux_n.p, sizeof(double) * 4 * nl, hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipMemcpyAsync(r->h_small + 4 * nl, r->d_f_total.p, sizeof(double) * nl, hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, sizeof(int), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  resolve_events(r);
+  r->small_valid = true;
+}
+
+bool check_dims(Radtran *r, int dim_T, int dim_P, int d1, int d2, int dim_dz, int has_p, int p1, int p2,
+                const double *pdens, const double *radii, char *err) {
+  // check_inputs / check_dimensions(_p), clima_radtran.f90:417-491 (same texts)
+  if (has_p && ((pdens && !radii) || (radii && !pdens))) { set_err(err, "Both pdensities and radii must be arguments."); return false; }
+  if (r->np > 0 && (!has_p || !radii)) { set_err(err, "The model contains particles but \"pdensities\" and \"radii\" are not arguments."); return false; }
+  if (dim_T != r->nz) { set_err(err, "\"T\" has the wrong input dimension."); return false; }
+  if (dim_P != r->nz) { set_err(err, "\"P\" has the wrong input dimension."); return false; }
+  if (d1 != r->nz || d2 != r->nsp) { set_err(err, "\"densities\" has the wrong input dimension."); return false; }
+  if (dim_dz != r->nz) { set_err(err, "\"dz\" has the wrong input dimension."); return false; }
+  if (has_p && radii) {
+    if (p1 != r->nz || p2 != r->np) { set_err(err, "\"pdensities\" has the wrong input dimension."); return false; }
+  }
+  return true;
+}
+
+void do_upload(Radtran *r, double T_surface, const double *T, const double *P, const double *dens,
+               const double *dz, const double *pdens, const double *radii) {
+  const int nz = r->nz;
+  double *h = r->h_col;
+  h[0] = T_surface;
+  std::memcpy(h + 1, T, sizeof(double) * nz);
+  std::memcpy(h + 1 + nz, P, sizeof(double) * nz);
+  std::memcpy(h + 1 + 2 * nz, dz, sizeof(double) * nz);
+  std::memcpy(h + 1 + 3 * nz, dens, sizeof(double) * (size_t)nz * r->nsp);
+  double *hp = h + 1 + 3 * nz + (size_t)nz * r->nsp;
+  if (r->np > 0 && pdens && radii) {
+    std::memcpy(hp, pdens, sizeof(double) * (size_t)nz * r->np);
+    std::memcpy(hp + (size_t)nz * r->np, radii, sizeof(double) * (size_t)nz * r->np);
+  }
+  r->column_has_particles = (pdens && radii);
+  HIPCHK(hipMemcpyAsync(r->d_col.p, h, sizeof(double) * r->col_count, hipMemcpyHostToDevice, r->stream));
+  // the staging buffer is reused by the next upload: wait for the copy (tiny)
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->last_T.assign(T, T + nz);
+  r->last_P.assign(P, P + nz);
+  if (r->np > 0 && radii) r->last_radii.assign(radii, radii + (size_t)nz * r->np); else r->last_radii.clear();
+  r->column_loaded = true;
+}
+
+bool surface_device_error(Radtran *r, char *err) {
+  if (*r->h_errflag != 0) {
+    // clima_radtran_types.f90:773-776
+    set_err(err, "Opacity computation failed in one or more wavelength bins.");
+    return true;
+  }
+  return false;
+}
+
+void get2d(WrkObj *w, DevBuf<double> &buf, int dim1, int dim2, double *arr) {
+  Radtran *r = w->parent;
+  HIPCHK(hipStreamSynchronize(r->stream));
+  resolve_events(r);
+  size_t n = std::min((size_t)dim1 * dim2, buf.n);
+  if (n) HIPCHK(hipMemcpy(arr, buf.p, n * sizeof(double), hipMemcpyDeviceToHost));
+}
+
+}  // namespace
+
+#define GUARD(r, ptr, err)                                   \
+  Radtran *r = as_rad(ptr);                                  \
+  if (!r) { set_err(err, "invalid Radtran handle"); return; }
+#define TRY try {
+#define CATCH(err) } catch (const HipFail &f) { set_err(err, f.msg); } catch (const std::exception &e) { set_err(err, e.what()); }
+
+extern "C" {
+
+void allocate_radtran(void **ptr) { *ptr = new Radtran(); }
+void deallocate_radtran(void *ptr) {
+  Radtran *r = as_rad(ptr);
+  if (r) delete r;
+}
+
+void radtran_create_begin(void *ptr, const int *nz, const int *nsp, const int *np, const int *nw,
+                          const double *wavl, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (*nz < 1) { set_err(err, "\"nz\" can not be less than 1."); return; }  // clima_radtran.f90:149-152
+  if (*nw < 1 || *nsp < 1 || *np < 0) { set_err(err, "invalid dimensions"); return; }
+  if (*np > MAX_PART) { set_err(err, "too many particle species for this build"); return; }
+  r->nz = *nz; r->nsp = *nsp; r->np = *np; r->nw = *nw;
+  r->wavl.assign(wavl, wavl + *nw + 1);
+  r->freq.resize(*nw + 1);
+  for (int i = 0; i < *nw + 1; i++) r->freq[i] = C_LIGHT / (wavl[i] * 1.0e-9);  // types_create.f90:361
+  r->state = 1;
+}
+
+void radtran_add_ktable(void *ptr, const int *sp_ind, const int *ngauss, const double *weights,
+                        const int *npress, const double *log10P, const int *ntemp, const double *temp,
+                        const double *log10k, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 1) { set_err(err, "radtran_add_ktable: call between create_begin and create_end"); return; }
+  if (*sp_ind < 1 || *sp_ind > r->nsp) { set_err(err, "k-distribution species index out of range"); return; }
+  if ((int)r->k.size() >= MAX_K) { set_err(err, "too many k-distributions for this build"); return; }
+  if (!r->k.empty() && *ngauss != r->ng) { set_err(err, "all k-distributions must share the same g-points"); return; }
+  if (*npress < 2 || *ntemp < 2) { set_err(err, "k-distribution grids need at least 2 nodes"); return; }
+  auto *k = new KTabHost();
+  k->sp = *sp_ind - 1; k->ng = *ngauss; k->nP = *npress; k->nT = *ntemp;
+  k->weights.assign(weights, weights + *ngauss);
+  k->log10P.assign(log10P, log10P + *npress);
+  k->temp.assign(temp, temp + *ntemp);
+  k->log10k.assign(log10k, log10k + (size_t)r->nw * *ntemp * *npress * *ngauss);
+  if (r->k.empty()) {  // create_Ksettings, types_create.f90:191-224; weight_e :1303-1304
+    r->ng = *ngauss;
+    r->wbin = k->weights;
+    r->wbin_e.assign(r->ng + 1, 0.0);
+    for (int i = 1; i < r->ng + 1; i++) r->wbin_e[i] = r->wbin[i - 1] + r->wbin_e[i - 1];
+    r->wxy.assign((size_t)r->ng * r->ng, 0.0);
+    for (int i = 0; i < r->ng; i++)
+      for (int j = 0; j < r->ng; j++) r->wxy[j + (size_t)i * r->ng] = r->wbin[i] * r->wbin[j];
+  }
+  r->k.push_back(k);
+}
+
+void radtran_add_xsection(void *ptr, const int *xs_type, const int *dim, const int *sp_ind1,
+                          const int *sp_ind2, const int *ntemp, const double *temp, const double *data,
+                          char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 1) { set_err(err, "radtran_add_xsection: call between create_begin and create_end"); return; }
+  std::vector<XsHost *> *list;
+  if (*xs_type == CLIMA_XS_CIA) list = &r->cia;
+  else if (*xs_type == CLIMA_XS_RAYLEIGH) list = &r->ray;
+  else if (*xs_type == CLIMA_XS_PHOTOLYSIS || *xs_type == CLIMA_XS_ABSORPTION) list = &r->pxs;
+  else { set_err(err, "unknown cross-section type"); return; }
+  if ((int)list->size() >= MAX_XS) { set_err(err, "too many cross sections for this build"); return; }
+  if (*dim != 0 && *dim != 1) { set_err(err, "cross-section dim must be 0 or 1"); return; }
+  if (*xs_type == CLIMA_XS_RAYLEIGH && *dim != 0) { set_err(err, "Rayleigh cross sections are 0-D"); return; }
+  if (*sp_ind1 < 1 || *sp_ind1 > r->nsp) { set_err(err, "cross-section species index out of range"); return; }
+  if (*xs_type == CLIMA_XS_CIA && (*sp_ind2 < 1 || *sp_ind2 > r->nsp)) { set_err(err, "CIA species index out of range"); return; }
+  if (*dim == 1 && *ntemp < 2) { set_err(err, "1-D cross sections need at least 2 temperatures"); return; }
+  auto *x = new XsHost();
+  x->type = *xs_type; x->dim = *dim; x->sp1 = *sp_ind1 - 1; x->sp2 = (*xs_type == CLIMA_XS_CIA) ? *sp_ind2 - 1 : -1;
+  x->nT = *dim ? *ntemp : 0;
+  if (*dim) x->temp.assign(temp, temp + *ntemp);
+  x->data.assign(data, data + (*dim ? (size_t)r->nw * *ntemp : (size_t)r->nw));
+  list->push_back(x);
+}
+
+void radtran_set_water_continuum(void *ptr, const int *LH2O, const int *ntemp, const double *temp,
+                                 const double *log10_xs_H2O, const double *log10_xs_foreign, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 1) { set_err(err, "radtran_set_water_continuum: call between create_begin and create_end"); return; }
+  if (*LH2O < 1 || *LH2O > r->nsp || *ntemp < 2) { set_err(err, "invalid water continuum arguments"); return; }
+  r->has_cont = true; r->LH2O = *LH2O - 1; r->cont_nT = *ntemp;
+  r->cont_temp.assign(temp, temp + *ntemp);
+  r->cont_H2O.assign(log10_xs_H2O, log10_xs_H2O + (size_t)r->nw * *ntemp);
+  r->cont_foreign.assign(log10_xs_foreign, log10_xs_foreign + (size_t)r->nw * *ntemp);
+}
+
+void radtran_add_particle(void *ptr, const int *p_ind, const int *nrad, const double *radii,
+                          const double *w0, const double *qext, const double *gt, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 1) { set_err(err, "radtran_add_particle: call between create_begin and create_end"); return; }
+  if (*p_ind < 1 || *p_ind > r->np || *nrad < 2) { set_err(err, "invalid particle arguments"); return; }
+  if ((int)r->part.size() >= MAX_PART) { set_err(err, "too many particles for this build"); return; }
+  auto *p = new PartHost();
+  p->p_ind = *p_ind - 1; p->nrad = *nrad;
+  size_t n = (size_t)r->nw * *nrad;
+  p->radii.assign(radii, radii + *nrad);
+  p->w0.assign(w0, w0 + n); p->qext.assign(qext, qext + n); p->gt.assign(gt, gt + n);
+  r->part.push_back(p);
+}
+
+void radtran_set_channels(void *ptr, const int *n_ir_edges, const double *ir_wavl, const int *n_sol_edges,
+                          const double *sol_wavl, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 1) { set_err(err, "radtran_set_channels: call between create_begin and create_end"); return; }
+  if (*n_ir_edges < 2 || *n_sol_edges < 2) { set_err(err, "channels need at least one bin"); return; }
+  if (!make_channel(r, r->ir, 0, *n_ir_edges, ir_wavl, err)) return;
+  if (!make_channel(r, r->sol, 1, *n_sol_edges, sol_wavl, err)) return;
+}
+
+void radtran_set_photons_sol(void *ptr, const int *n, const double *photons_sol, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->sol.nw == 0 || *n != r->sol.nw) { set_err(err, "\"photons_sol\" has the wrong size"); return; }
+  r->photons_sol.assign(photons_sol, photons_sol + *n);
+  r->fields_dirty = true;
+}
+
+void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *surface_albedo, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 1) { set_err(err, "radtran_create_end: create_begin has not been called"); return; }
+  if (r->k.empty()) { set_err(err, "There are no k-distributions, yet there must be some to compute total opacity."); return; }
+  if (r->ir.nw == 0 || r->sol.nw == 0) { set_err(err, "wavelength channels are not set"); return; }
+  if (*num_zenith_angles < 1) { set_err(err, "number of zenith angles must be >= 1"); return; }
+  TRY
+  const int nz = r->nz, nw = r->nw, ng = r->ng;
+  // zenith_angles_and_weights (clima_eqns.f90:26-41) then cos(deg*pi/180) (clima_radtran.f90:165)
+  std::vector<double> x, w;
+  gauss_legendre(*num_zenith_angles, x, w);
+  r->zenith_u.resize(*num_zenith_angles);
+  r->zenith_w.resize(*num_zenith_angles);
+  for (int i = 0; i < *num_zenith_angles; i++) {
+    double mu = x[i] / 2.0 + 1.0 / 2.0;
+    double ang = std::acos(mu) * 180.0 / PI;
+    r->zenith_w[i] = w[i] / 2.0;
+    r->zenith_u[i] = std::cos(ang * PI / 180.0);
+  }
+  r->surface_albedo.assign(r->sol.nw, *surface_albedo);   // :182-183
+  r->surface_emissivity.assign(r->ir.nw, 1.0);            // :185-186
+  if (r->photons_sol.empty()) r->photons_sol.assign(r->sol.nw, 0.0);
+
+  int dev_count = 0;
+  HIPCHK(hipGetDeviceCount(&dev_count));
+  if (dev_count < 1) throw HipFail{"no HIP device available: the Radtran hot path has no CPU fallback"};
+  HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+
+  // ---- tables to HBM + interpolation slots
+  r->slots.clear();
+  auto add_slot = [&](const double *axis_dev, const std::vector<double> &axis, int source, bool flag) {
+    SlotDev s;
+    s.axis = axis_dev; s.n = (int)axis.size(); s.source = source;
+    s.lo = *std::min_element(axis.begin(), axis.end());   // types_create.f90:1371-1375
+    s.hi = *std::max_element(axis.begin(), axis.end());
+    s.flag_clamp = flag ? 1 : 0;
+    r->slots.push_back(s);
+  };
+  for (auto *k : r->k) {
+    k->d_log10k.upload(k->log10k); k->d_log10P.upload(k->log10P); k->d_temp.upload(k->temp);
+    add_slot(k->d_log10P.p, k->log10P, 0, false);
+    add_slot(k->d_temp.p, k->temp, 1, false);
+  }
+  for (auto *v : {&r->cia, &r->pxs})
+    for (auto *xs : *v) {
+      xs->d_data.upload(xs->data);
+      if (xs->dim) { xs->d_temp.upload(xs->temp); add_slot(xs->d_temp.p, xs->temp, 1, false); }
+    }
+  for (auto *xs : r->ray) xs->d_data.upload(xs->data);
+  if (r->has_cont) {
+    r->d_cont_temp.upload(r->cont_temp); r->d_cont_H2O.upload(r->cont_H2O); r->d_cont_foreign.upload(r->cont_foreign);
+    add_slot(r->d_cont_temp.p, r->cont_temp, 1, false);
+  }
+  for (auto *p : r->part) {
+    p->d_radii.upload(p->radii); p->d_w0.upload(p->w0); p->d_qext.upload(p->qext); p->d_gt.upload(p->gt);
+    add_slot(p->d_radii.p, p->radii, 2 + p->p_ind, true);
+  }
+  r->nslots = (int)r->slots.size();
+  if (r->nslots > MAX_SLOTS) throw HipFail{"too many interpolated tables for this build"};
+  r->d_wbin.upload(r->wbin); r->d_wbin_e.upload(r->wbin_e); r->d_wxy.upload(r->wxy);
+  r->d_freq.upload(r->freq);
+  r->ir.d_freq.upload(r->ir.freq); r->sol.d_freq.upload(r->sol.freq);
+  // amean unit factors per solar bin (radiate.f90:174-178)
+  std::vector<double> f1(r->sol.nw), f2(r->sol.nw), dw(r->sol.nw);
+  for (int l = 0; l < r->sol.nw; l++) {
+    double avg_freq = 0.5 * (r->sol.freq[l] + r->sol.freq[l + 1]);
+    double avg_wavl = 1.0e9 * C_LIGHT / avg_freq;
+    f1[l] = (avg_freq / avg_wavl);
+    f2[l] = (avg_wavl / (PLANK * C_LIGHT * 1.0e16));
+    dw[l] = (r->sol.wavl[l + 1] - r->sol.wavl[l]);
+  }
+  r->d_am_f1.upload(f1); r->d_am_f2.upload(f2); r->d_am_dw.upload(dw);
+
+  // ---- column, prep, opr, results
+  r->col_count = 1 + (size_t)3 * nz + (size_t)nz * r->nsp + (size_t)2 * nz * r->np;
+  r->d_col.alloc(r->col_count);
+  r->d_col.zero();
+  HIPCHK(hipHostMalloc((void **)&r->h_col, sizeof(double) * r->col_count));
+  r->d_log10P.alloc(nz); r->d_cols.alloc((size_t)nz * r->nsp); r->d_foreign.alloc(nz);
+  r->d_src.alloc(nz); r->d_ix.alloc((size_t)std::max(1, r->nslots) * nz); r->d_q.alloc((size_t)std::max(1, r->nslots) * nz);
+  r->d_err.alloc(1); r->d_err.zero();
+  r->d_tau.alloc((size_t)nw * ng * nz); r->d_w0.alloc((size_t)nw * ng * nz);
+  r->d_g.alloc((size_t)nw * nz); r->d_tau_band.alloc((size_t)nw * nz);
+  r->d_tau.zero(); r->d_w0.zero(); r->d_g.zero(); r->d_tau_band.zero();
+  auto mk = [&](WrkObj &wk, int which, int nwc) {  // clima_radtran.f90:199-214
+    wk.parent = r; wk.which = which;
+    wk.fup_a.alloc((size_t)(nz + 1) * nwc); wk.fdn_a.alloc((size_t)(nz + 1) * nwc);
+    wk.amean.alloc((size_t)(nz + 1) * nwc); wk.tau_band.alloc((size_t)nz * nwc);
+    wk.fup_a.zero(); wk.fdn_a.zero(); wk.amean.zero(); wk.tau_band.zero();
+  };
+  mk(r->wrk_ir, 0, r->ir.nw);
+  mk(r->wrk_sol, 1, r->sol.nw);
+  r->d_flux_n.alloc((size_t)4 * (nz + 1)); r->d_flux_n.zero();
+  r->d_f_total.alloc(nz + 1); r->d_f_total.zero();
+  HIPCHK(hipHostMalloc((void **)&r->h_small, sizeof(double) * 5 * (nz + 1)));
+  std::memset(r->h_small, 0, sizeof(double) * 5 * (nz + 1));
+  HIPCHK(hipHostMalloc((void **)&r->h_errflag, sizeof(int)));
+  *r->h_errflag = 0;
+  r->f_total.assign(nz + 1, 0.0);
+  HIPCHK(hipDeviceSynchronize());
+  r->fields_dirty = true;
+  compute_shard(r);
+  r->small_valid = true;
+  r->state = 2;
+  CATCH(err)
+}
+
+void radtran_upload_column(void *ptr, const double *T_surface, const double *T, const double *P,
+                           const double *densities, const double *dz, const double *pdensities,
+                           const double *radii, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  if (r->np > 0 && (!pdensities || !radii)) { set_err(err, "The model contains particles but \"pdensities\" and \"radii\" are not arguments."); return; }
+  TRY
+  do_upload(r, *T_surface, T, P, densities, dz, pdensities, radii);
+  CATCH(err)
+}
+
+void radtran_radiate_resident(void *ptr, const int *compute_solar, const int *compute_opacity, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  if (!r->column_loaded) { set_err(err, "no column has been uploaded"); return; }
+  TRY
+  enqueue_radiate(r, *compute_solar != 0, *compute_opacity != 0);
+  CATCH(err)
+}
+
+void radtran_synchronize(void *ptr, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  TRY
+  HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, sizeof(int), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  resolve_events(r);
+  surface_device_error(r, err);
+  CATCH(err)
+}
+
+void radtran_radiate_wrapper(void *ptr, const double *T_surface, const int *dim_T, const double *T,
+                             const int *dim_P, const double *P, const int *dim1_d, const int *dim2_d,
+                             const double *densities, const int *dim_dz, const double *dz,
+                             const int *has_particles, const int *dim1_p, const int *dim2_p,
+                             const double *pdensities, const double *radii, const int *compute_solar,
+                             const int *compute_opacity, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  const int hp = has_particles ? *has_particles : 0;
+  if (!check_dims(r, *dim_T, *dim_P, *dim1_d, *dim2_d, *dim_dz, hp, dim1_p ? *dim1_p : 0, dim2_p ? *dim2_p : 0,
+                  hp ? pdensities : nullptr, hp ? radii : nullptr, err))
+    return;
+  TRY
+  do_upload(r, *T_surface, T, P, densities, dz, hp ? pdensities : nullptr, hp ? radii : nullptr);
+  enqueue_radiate(r, *compute_solar != 0, *compute_opacity != 0);
+  fetch_small(r);
+  if (surface_device_error(r, err)) return;
+  const int nl = r->nz + 1;
+  for (int i = 0; i < nl; i++) r->f_total[i] = r->h_small[4 * nl + i];
+  CATCH(err)
+}
+
+void radtran_toa_fluxes_wrapper(void *ptr, const double *T_surface, const int *dim_T, const double *T,
+                                const int *dim_P, const double *P, const int *dim1_d, const int *dim2_d,
+                                const double *densities, const int *dim_dz, const double *dz,
+                                const int *has_particles, const int *dim1_p, const int *dim2_p,
+                                const double *pdensities, const double *radii, const int *compute_solar,
+                                const int *compute_opacity, double *ISR, double *OLR, char *err) {
+  radtran_radiate_wrapper(ptr, T_surface, dim_T, T, dim_P, P, dim1_d, dim2_d, densities, dim_dz, dz,
+                          has_particles, dim1_p, dim2_p, pdensities, radii, compute_solar, compute_opacity, err);
+  if (err && err[0]) return;
+  Radtran *r = as_rad(ptr);
+  if (!r) return;
+  const int nl = r->nz + 1, nz = r->nz;
+  // clima_radtran.f90:339-340
+  *ISR = (r->h_small[3 * nl + nz] - r->h_small[2 * nl + nz]);
+  *OLR = -(r->h_small[1 * nl + nz] - r->h_small[0 * nl + nz]);
+}
+
+void radtran_apply_radiation_enhancement(void *ptr, const double *rad_enhancement) {
+  Radtran *r = as_rad(ptr);
+  if (!r || r->state != 2) return;
+  try {  // clima_radtran.f90:402-411
+    const int nl = r->nz + 1;
+    launch_scale(r->wrk_sol.fdn_a.p, r->wrk_sol.fdn_a.n, *rad_enhancement, r->stream);
+    launch_scale(r->wrk_sol.fup_a.p, r->wrk_sol.fup_a.n, *rad_enhancement, r->stream);
+    launch_scale(r->d_flux_n.p + 2 * nl, (size_t)2 * nl, *rad_enhancement, r->stream);
+    launch_f_total(r->nz, r->d_flux_n.p, r->d_f_total.p, r->stream);
+    r->small_valid = false;
+    fetch_small(r);
+    for (int i = 0; i < nl; i++) r->f_total[i] = r->h_small[4 * nl + i];
+  } catch (...) {
+  }
+}
+
+void radtran_flux_device_ptr(void *ptr, void **dptr, int *count) {
+  Radtran *r = as_rad(ptr);
+  *dptr = r ? (void *)r->d_flux_n.p : nullptr;
+  *count = r ? 4 * (r->nz + 1) : 0;
+}
+
+void radtran_set_bin_shard(void *ptr, const int *rank, const int *world, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  if (*world < 1 || *rank < 0 || *rank >= *world) { set_err(err, "invalid shard (rank, world)"); return; }
+  TRY
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->shard_rank = *rank; r->shard_world = *world;
+  compute_shard(r);
+  // bins outside the shard hold zeros so that sharded per-bin spectra add up across ranks
+  for (WrkObj *w : {&r->wrk_ir, &r->wrk_sol}) { w->fup_a.zero(r->stream); w->fdn_a.zero(r->stream); w->amean.zero(r->stream); w->tau_band.zero(r->stream); }
+  r->d_flux_n.zero(r->stream);
+  HIPCHK(hipStreamSynchronize(r->stream));
+  CATCH(err)
+}
+
+void radtran_finish_reduced(void *ptr, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  TRY
+  launch_f_total(r->nz, r->d_flux_n.p, r->d_f_total.p, r->stream);
+  r->small_valid = false;
+  CATCH(err)
+}
+
+void radtran_stream_get(void *ptr, void **stream) {
+  Radtran *r = as_rad(ptr);
+  *stream = r ? (void *)r->stream : nullptr;
+}
+
+void radtran_profile_set(void *ptr, const int *enable) {
+  Radtran *r = as_rad(ptr);
+  if (r) r->profile = (*enable != 0);
+}
+void radtran_profile_reset(void *ptr) {
+  Radtran *r = as_rad(ptr);
+  if (!r) return;
+  for (int i = 0; i < 4; i++) { r->k_ms[i] = 0; r->k_n[i] = 0; }
+}
+void radtran_kernel_time_get(void *ptr, const int *kernel_id, double *ms_total, int *launches, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (*kernel_id < 0 || *kernel_id > 3) { set_err(err, "kernel id out of range"); return; }
+  TRY
+  if (!r->pending.empty()) { HIPCHK(hipStreamSynchronize(r->stream)); resolve_events(r); }
+  *ms_total = r->k_ms[*kernel_id];
+  *launches = r->k_n[*kernel_id];
+  CATCH(err)
+}
+
+void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double *bytes_in, double *bytes_out,
+                               double *bytes_tables_full, char *err) {
+  // B_alg = B_tab(distinct interpolation nodes touched by the column)
+  // + B_in + B_out; intermediates (opr) get no credit.
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2 || !r->column_loaded) { set_err(err, "no column has been uploaded"); return; }
+  const int nz = r->nz;
+  const double nw = r->nw;
+  double distinct = 0.0, full = 0.0;
+  auto nodes1d = [&](const std::vector<double> &axis, const std::vector<double> &vals) {
+    std::set<int> s;
+    double lo = *std::min_element(axis.begin(), axis.end()), hi = *std::max_element(axis.begin(), axis.end());
+    for (double v : vals) { int i = host_bracket(axis, std::min(std::max(v, lo), hi)); s.insert(i); s.insert(i + 1); }
+    return (double)s.size();
+  };
+  std::vector<double> lp(nz);
+  for (int j = 0; j < nz; j++) lp[j] = std::log10(r->last_P[j]);
+  for (auto *k : r->k) {
+    std::set<std::pair<int, int>> s;
+    double plo = *std::min_element(k->log10P.begin(), k->log10P.end()), phi = *std::max_element(k->log10P.begin(), k->log10P.end());
+    double tlo = *std::min_element(k->temp.begin(), k->temp.end()), thi = *std::max_element(k->temp.begin(), k->temp.end());
+    for (int j = 0; j < nz; j++) {
+      int iP = host_bracket(k->log10P, std::min(std::max(lp[j], plo), phi));
+      int iT = host_bracket(k->temp, std::min(std::max(r->last_T[j], tlo), thi));
+      for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) s.insert({iP + a, iT + b});
+    }
+    distinct += 8.0 * k->ng * nw * (double)s.size();
+    full += 8.0 * k->ng * nw * k->nP * k->nT;
+  }
+  for (auto *v : {&r->cia, &r->pxs, &r->ray})
+    for (auto *xs : *v) {
+      if (xs->dim) { distinct += 8.0 * nw * nodes1d(xs->temp, r->last_T); full += 8.0 * nw * xs->nT; }
+      else { distinct += 8.0 * nw; full += 8.0 * nw; }
+    }
+  if (r->has_cont) { distinct += 2 * 8.0 * nw * nodes1d(r->cont_temp, r->last_T); full += 2 * 8.0 * nw * r->cont_nT; }
+  for (auto *p : r->part) {
+    if (!r->last_radii.empty()) {
+      std::vector<double> rr(r->last_radii.begin() + (size_t)p->p_ind * nz, r->last_radii.begin() + (size_t)(p->p_ind + 1) * nz);
+      distinct += 3 * 8.0 * nw * nodes1d(p->radii, rr);
+    }
+    full += 3 * 8.0 * nw * p->nrad;
+  }
+  const int nzen = (int)r->zenith_u.size();
+  *bytes_tables_distinct = distinct;
+  *bytes_tables_full = full;
+  *bytes_in = 8.0 * (nz * (3.0 + r->nsp + 2.0 * r->np) + 2.0 * nw + nzen * 2.0 + r->sol.nw);
+  *bytes_out = 8.0 * ((2.0 * (nz + 1) + nz) * r->ir.nw + (3.0 * (nz + 1) + nz) * r->sol.nw + 5.0 * (nz + 1));
+}
+
+void radtran_opr_get(void *ptr, double *tau, double *w0, double *g, double *tau_band, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  TRY
+  HIPCHK(hipStreamSynchronize(r->stream));
+  resolve_events(r);
+  if (tau) HIPCHK(hipMemcpy(tau, r->d_tau.p, r->d_tau.n * sizeof(double), hipMemcpyDeviceToHost));
+  if (w0) HIPCHK(hipMemcpy(w0, r->d_w0.p, r->d_w0.n * sizeof(double), hipMemcpyDeviceToHost));
+  if (g) HIPCHK(hipMemcpy(g, r->d_g.p, r->d_g.n * sizeof(double), hipMemcpyDeviceToHost));
+  if (tau_band) HIPCHK(hipMemcpy(tau_band, r->d_tau_band.p, r->d_tau_band.n * sizeof(double), hipMemcpyDeviceToHost));
+  CATCH(err)
+}
+
+// ---- reference-named getters / setters (clima/fortran/Radtran.f90) -------------------
+
+static double bolometric(Radtran *r) {  // Radtran_bolometric_flux, clima_radtran.f90:353-364
+  double flux = 0.0;
+  for (int i = 0; i < r->sol.nw; i++) flux = flux + r->photons_sol[i] * (r->sol.freq[i] - r->sol.freq[i + 1]);
+  return r->photon_scale_factor * flux / 1.0e3;
+}
+void radtran_set_bolometric_flux_wrapper(void *ptr, const double *flux) {  // :345-350
+  Radtran *r = as_rad(ptr);
+  if (!r) return;
+  r->photon_scale_factor = 1.0;
+  r->photon_scale_factor = *flux / bolometric(r);
+}
+void radtran_bolometric_flux_wrapper(void *ptr, double *flux) {
+  Radtran *r = as_rad(ptr);
+  if (r) *flux = bolometric(r);
+}
+static double equilibrium_temperature(double stellar_radiation, double bond_albedo) {  // clima_eqns.f90:248-254
+  return std::pow((stellar_radiation * (1.0 - bond_albedo)) / (4.0 * SIGMA_SI), 0.25);
+}
+void radtran_skin_temperature_wrapper(void *ptr, const double *bond_albedo, double *T_skin) {  // clima_eqns.f90:256-261
+  Radtran *r = as_rad(ptr);
+  if (r) *T_skin = equilibrium_temperature(bolometric(r), *bond_albedo) * std::pow(0.5, 0.25);
+}
+void radtran_equilibrium_temperature_wrapper(void *ptr, const double *bond_albedo, double *T_eq) {
+  Radtran *r = as_rad(ptr);
+  if (r) *T_eq = equilibrium_temperature(bolometric(r), *bond_albedo);
+}
+
+#define VEC_GETSET(name, field)                                                                 \
+  void radtran_##name##_get_size(void *ptr, int *dim1) {                                        \
+    Radtran *r = as_rad(ptr);                                                                   \
+    *dim1 = r ? (int)r->field.size() : 0;                                                       \
+  }                                                                                             \
+  void radtran_##name##_get(void *ptr, const int *dim1, double *arr) {                          \
+    Radtran *r = as_rad(ptr);                                                                   \
+    if (!r) return;                                                                             \
+    for (int i = 0; i < *dim1 && i < (int)r->field.size(); i++) arr[i] = r->field[i];           \
+  }                                                                                             \
+  void radtran_##name##_set(void *ptr, const int *dim1, const double *arr) {                    \
+    Radtran *r = as_rad(ptr);                                                                   \
+    if (!r) return;                                                                             \
+    for (int i = 0; i < *dim1 && i < (int)r->field.size(); i++) r->field[i] = arr[i];           \
+    r->fields_dirty = true;                                                                     \
+  }
+VEC_GETSET(zenith_u, zenith_u)
+VEC_GETSET(surface_albedo, surface_albedo)
+VEC_GETSET(surface_emissivity, surface_emissivity)
+
+void radtran_zenith_weights_get(void *ptr, const int *dim1, double *arr) {
+  Radtran *r = as_rad(ptr);
+  if (!r) return;
+  for (int i = 0; i < *dim1 && i < (int)r->zenith_w.size(); i++) arr[i] = r->zenith_w[i];
+}
+void radtran_zenith_weights_set(void *ptr, const int *dim1, const double *arr) {
+  Radtran *r = as_rad(ptr);
+  if (!r) return;
+  for (int i = 0; i < *dim1 && i < (int)r->zenith_w.size(); i++) r->zenith_w[i] = arr[i];
+  r->fields_dirty = true;
+}
+void radtran_has_hard_surface_get(void *ptr, int *val) { Radtran *r = as_rad(ptr); if (r) *val = r->has_hard_surface ? 1 : 0; }
+void radtran_has_hard_surface_set(void *ptr, const int *val) { Radtran *r = as_rad(ptr); if (r) r->has_hard_surface = (*val != 0); }
+void radtran_photon_scale_factor_get(void *ptr, double *val) { Radtran *r = as_rad(ptr); if (r) *val = r->photon_scale_factor; }
+void radtran_photon_scale_factor_set(void *ptr, const double *val) { Radtran *r = as_rad(ptr); if (r) r->photon_scale_factor = *val; }
+void radtran_ir_tau_min_get(void *ptr, double *val) { Radtran *r = as_rad(ptr); if (r) *val = r->ir_tau_min; }
+void radtran_ir_tau_min_set(void *ptr, const double *val) { Radtran *r = as_rad(ptr); if (r) r->ir_tau_min = *val; }
+void radtran_diurnal_fac_get(void *ptr, double *val) { Radtran *r = as_rad(ptr); if (r) *val = r->diurnal_fac; }
+void radtran_diurnal_fac_set(void *ptr, const double *val) { Radtran *r = as_rad(ptr); if (r) r->diurnal_fac = *val; }
+void radtran_ir_get(void *ptr, void **ptr1) { Radtran *r = as_rad(ptr); *ptr1 = r ? (void *)&r->ir : nullptr; }
+void radtran_sol_get(void *ptr, void **ptr1) { Radtran *r = as_rad(ptr); *ptr1 = r ? (void *)&r->sol : nullptr; }
+void radtran_wrk_ir_get(void *ptr, void **ptr1) { Radtran *r = as_rad(ptr); *ptr1 = r ? (void *)&r->wrk_ir : nullptr; }
+void radtran_wrk_sol_get(void *ptr, void **ptr1) { Radtran *r = as_rad(ptr); *ptr1 = r ? (void *)&r->wrk_sol : nullptr; }
+void radtran_f_total_get_size(void *ptr, int *dim1) { Radtran *r = as_rad(ptr); *dim1 = r ? r->nz + 1 : 0; }
+void radtran_f_total_get(void *ptr, const int *dim1, double *arr) {
+  Radtran *r = as_rad(ptr);
+  if (!r || r->state != 2) return;
+  try {
+    fetch_small(r);
+    for (int i = 0; i < *dim1 && i < r->nz + 1; i++) arr[i] = r->h_small[4 * (r->nz + 1) + i];
+  } catch (...) {
+  }
+}
+void radtran_photons_sol_get_size(void *ptr, int *dim1) { Radtran *r = as_rad(ptr); *dim1 = r ? (int)r->photons_sol.size() : 0; }
+void radtran_photons_sol_get(void *ptr, const int *dim1, double *arr) {
+  Radtran *r = as_rad(ptr);
+  if (!r) return;
+  for (int i = 0; i < *dim1 && i < (int)r->photons_sol.size(); i++) arr[i] = r->photons_sol[i];
+}
+
+// ---- ClimaRadtranWrk (clima/fortran/ClimaRadtranWrk.f90) ------------------------------
+static int ch_nw(WrkObj *w) { return w->which ? w->parent->sol.nw : w->parent->ir.nw; }
+#define WRK2D(name, field, rows)                                                          \
+  void climaradtranwrk_##name##_get_size(void *ptr, int *dim1, int *dim2) {               \
+    WrkObj *w = reinterpret_cast<WrkObj *>(ptr);                                          \
+    *dim1 = w->parent->nz + (rows);                                                       \
+    *dim2 = ch_nw(w);                                                                     \
+  }                                                                                       \
+  void climaradtranwrk_##name##_get(void *ptr, const int *dim1, const int *dim2, double *arr) { \
+    WrkObj *w = reinterpret_cast<WrkObj *>(ptr);                                          \
+    try { get2d(w, w->field, *dim1, *dim2, arr); } catch (...) {}                          \
+  }
+WRK2D(fup_a, fup_a, 1)
+WRK2D(fdn_a, fdn_a, 1)
+WRK2D(amean, amean, 1)
+WRK2D(tau_band, tau_band, 0)
+#define WRK1D(name, up)                                                                   \
+  void climaradtranwrk_##name##_get_size(void *ptr, int *dim1) {                          \
+    WrkObj *w = reinterpret_cast<WrkObj *>(ptr);                                          \
+    *dim1 = w->parent->nz + 1;                                                            \
+  }                                                                                       \
+  void climaradtranwrk_##name##_get(void *ptr, const int *dim1, double *arr) {            \
+    WrkObj *w = reinterpret_cast<WrkObj *>(ptr);                                          \
+    Radtran *r = w->parent;                                                               \
+    try {                                                                                 \
+      fetch_small(r);                                                                     \
+      const int nl = r->nz + 1;                                                           \
+      const int a = (w->which ? 2 : 0) + ((up) ? 0 : 1);                                  \
+      for (int i = 0; i < *dim1 && i < nl; i++) arr[i] = r->h_small[a * nl + i];          \
+    } catch (...) {}                                                                      \
+  }
+WRK1D(fup_n, 1)
+WRK1D(fdn_n, 0)
+
+// ---- RTChannel (clima/fortran/RTChannel.f90) ------------------------------------------
+void rtchannel_wavl_get_size(void *ptr, int *dim1) { *dim1 = (int)reinterpret_cast<ChannelObj *>(ptr)->wavl.size(); }
+void rtchannel_wavl_get(void *ptr, const int *dim1, double *arr) {
+  ChannelObj *c = reinterpret_cast<ChannelObj *>(ptr);
+  for (int i = 0; i < *dim1 && i < (int)c->wavl.size(); i++) arr[i] = c->wavl[i];
+}
+void rtchannel_freq_get_size(void *ptr, int *dim1) { *dim1 = (int)reinterpret_cast<ChannelObj *>(ptr)->freq.size(); }
+void rtchannel_freq_get(void *ptr, const int *dim1, double *arr) {
+  ChannelObj *c = reinterpret_cast<ChannelObj *>(ptr);
+  for (int i = 0; i < *dim1 && i < (int)c->freq.size(); i++) arr[i] = c->freq[i];
+}
+
+}  // extern "C"

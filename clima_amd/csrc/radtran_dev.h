@@ -1,0 +1,143 @@
+// radtran_dev.h -- device-facing parameter blocks shared by the kernels and the host API.
+//
+// HBM layout (all f64 unless noted; "TOA-first" = index 0 is the top layer, as
+// OpticalPropertiesResult in src/radtran/clima_radtran_types.f90:242-247, :862-865):
+//
+//   tables   log10k[s]      [nw][nT][nP][ng]   (the on-disk order, types_create.f90:1349-1358;
+//                                               one (P,T) node = ng contiguous doubles = 64 B)
+//            xs 0-D         [nw]               Rayleigh / photolysis / constant CIA
+//            xs 1-D         [nw][nT]           log10 CIA, photolysis, H2O self/foreign continuum
+//            particles      [nw][nrad] x3      w0, qext, g
+//   column   T,P,dz [nz]; dens [nsp][nz]; pdens,radii [np][nz]   (ground-first, as the API)
+//   prep     log10P, cols [nsp][nz], foreign_col, src (pair_reuse source layer),
+//            per interpolation slot: left index ix[slot][nz] (i32) and weight q[slot][nz]
+//   opr      tau, w0        [nw][ng][nz]       TOA-first; == Fortran (nz,ng,nw) column-major
+//            g, tau_band    [nw][nz]
+//   results  fup_a, fdn_a, amean [nw_ch][nz+1]; tau_band [nw_ch][nz]   ground-first,
+//            == Fortran (nz+1,nw_ch) column-major (ClimaRadtranWrk, clima_radtran.f90:11-25)
+//            flux_n         [4][nz+1]          ir_up, ir_dn, sol_up, sol_dn (the all-reduce payload)
+//            f_total        [nz+1]
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace clima {
+
+constexpr int MAX_K = 8;      // k-distribution species
+constexpr int MAX_XS = 16;    // per Xsection kind
+constexpr int MAX_PART = 4;   // particle species
+constexpr int MAX_SLOTS = 2 * MAX_K + 2 * MAX_XS + 1 + MAX_PART;
+
+// src/clima_const.f90:9-21
+constexpr double PLANK = 6.62607004e-34;
+constexpr double C_LIGHT = 299792458.0;
+constexpr double K_BOLTZ_SI = 1.380649e-23;
+constexpr double PI = 3.14159265358979323846e0;
+constexpr double SIGMA_SI = 5.670374419e-8;
+// src/radtran/clima_radtran_types.f90:9-11
+constexpr double MAX_W0 = 0.99999;
+constexpr double MAX_GT = 0.999999;
+constexpr double TAU_MIN = 1.0e-20;
+constexpr double LN10 = 2.302585092994045684017991454684364207601;
+constexpr double TINY = 2.2250738585072014e-308;  // tiny(0.0_dp), clima_radtran_types.f90:558-562
+
+struct XsDev {
+  const double *data;  // dim 0: [nw]; dim 1: [nw][nT]
+  int dim, sp1, sp2, nT, slot;
+};
+
+struct KDev {
+  const double *log10k;  // [nw][nT][nP][ng]
+  int sp, nP, nT, slotP, slotT;
+};
+
+struct PartDev {
+  const double *w0, *qext, *gt;  // [nw][nrad]
+  int p_ind, nrad, slot;
+};
+
+// One interpolation axis evaluated per layer by the prep kernel: clamp, bracket
+// (dintrv semantics, linear_interpolation_module.F90:348-350), weight.
+struct SlotDev {
+  const double *axis;
+  int n;
+  int source;  // 0 = log10(P), 1 = T, 2+p = radius of particle column p
+  double lo, hi;
+  int flag_clamp;  // particles: out-of-range radius is an error (types.f90:973-976)
+};
+
+struct ColumnDev {
+  const double *T, *P, *dz, *dens, *pdens, *radii;  // dens [nsp][nz], pdens/radii [np][nz]
+  double *log10P, *cols, *foreign_col;
+  int *src;        // source layer for interpolation (j, or j-1 under pair_reuse)
+  int *ix;         // [nslots][nz]
+  double *q;       // [nslots][nz]
+  int *err_flag;   // device error word (bit 0: particle radius clamp)
+  const double *T_surface;  // device scalar
+};
+
+struct OpacityParams {
+  int nz, nw, ng, nsp, np;
+  int bin_lo, nbins;  // opacity bins handled by this launch
+  int nk, ncia, nray, npxs, npart, has_cont, LH2O, cont_slot, cont_nT;
+  KDev k[MAX_K];
+  XsDev cia[MAX_XS], ray[MAX_XS], pxs[MAX_XS];
+  PartDev part[MAX_PART];
+  const double *cont_H2O, *cont_foreign;  // [nw][nT]
+  const double *wbin, *wbin_e, *wxy;      // Ksettings (types.f90:84-94)
+  ColumnDev col;
+  double *tau, *w0, *g, *tau_band;        // opr
+};
+
+struct PrepParams {
+  int nz, nsp, np, nslots, has_cont, LH2O, check_radii;
+  SlotDev slots[MAX_SLOTS];
+  ColumnDev col;
+};
+
+struct TwoStreamParams {
+  int nz, ng;
+  // task list: blocks [0, n_sol) are solar bins sol_lo.., blocks [n_sol, n_sol+n_ir) IR bins
+  int n_sol, sol_lo, n_ir, ir_lo;          // channel-local first bin of this launch
+  int sol_start, ir_start;                 // channel -> opacity-bin offset (RTChannel%ind_start)
+  const double *tau, *w0, *g, *tau_band;   // opr
+  const double *wbin;
+  const double *freq;                      // opacity grid [nw+1]
+  // IR
+  const double *T, *T_surface;
+  const double *emissivity;                // [nw_ir]
+  int has_hard_surface;
+  double ir_tau_min;
+  // solar
+  int nzen;
+  const double *zen_u, *zen_w;
+  const double *albedo;                    // [nw_sol]
+  const double *photons_sol;               // [nw_sol], unscaled
+  double photon_scale_factor, diurnal_fac;
+  const double *am_f1, *am_f2, *am_dw;     // per solar bin amean unit factors (radiate.f90:174-178)
+  // outputs (channel-local bin index)
+  double *ir_fup_a, *ir_fdn_a, *ir_tau_band;
+  double *sol_fup_a, *sol_fdn_a, *sol_amean, *sol_tau_band;
+};
+
+struct IntegrateParams {
+  int nz;
+  int nw_ir, nw_sol;
+  int ir_lo, ir_n, sol_lo, sol_n;          // bins owned by this rank (all when unsharded)
+  int do_solar;
+  const double *ir_fup_a, *ir_fdn_a, *sol_fup_a, *sol_fdn_a;
+  const double *ir_freq, *sol_freq;        // channel freq [nw_ch+1]
+  double *flux_n;                          // [4][nz+1]
+  double *f_total;
+};
+
+// launchers (kernels.hip)
+void launch_prep(const PrepParams &p, hipStream_t s);
+// returns false when ng is unsupported by the compiled kernels
+bool launch_opacity(const OpacityParams &p, hipStream_t s);
+bool launch_twostream(const TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
+void launch_integrate(const IntegrateParams &p, hipStream_t s);
+void launch_f_total(int nz, const double *flux_n, double *f_total, hipStream_t s);
+void launch_scale(double *a, size_t n, double f, hipStream_t s);
+
+}  // namespace clima

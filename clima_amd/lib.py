@@ -1,0 +1,114 @@
+"""Loader for the HIP C-ABI library (include/clima_radtran_hip.h).
+
+There is no fallback: if the shared library is missing or does not load, importing the
+product path raises.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libclima_radtran_hip.so")
+ERR_LEN = 1024
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+_err = C.c_char_p
+
+# name -> argtypes, exactly as declared in include/clima_radtran_hip.h
+SIGNATURES = {
+    "allocate_radtran": [_vpp],
+    "deallocate_radtran": [_vp],
+    "radtran_create_begin": [_vp, _ip, _ip, _ip, _ip, _dp, _err],
+    "radtran_add_ktable": [_vp, _ip, _ip, _dp, _ip, _dp, _ip, _dp, _dp, _err],
+    "radtran_add_xsection": [_vp, _ip, _ip, _ip, _ip, _ip, _dp, _dp, _err],
+    "radtran_set_water_continuum": [_vp, _ip, _ip, _dp, _dp, _dp, _err],
+    "radtran_add_particle": [_vp, _ip, _ip, _dp, _dp, _dp, _dp, _err],
+    "radtran_set_channels": [_vp, _ip, _dp, _ip, _dp, _err],
+    "radtran_set_photons_sol": [_vp, _ip, _dp, _err],
+    "radtran_create_end": [_vp, _ip, _dp, _err],
+    "radtran_radiate_wrapper": [_vp, _dp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _dp,
+                                _ip, _ip, _err],
+    "radtran_toa_fluxes_wrapper": [_vp, _dp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _dp,
+                                   _ip, _ip, _dp, _dp, _err],
+    "radtran_apply_radiation_enhancement": [_vp, _dp],
+    "radtran_upload_column": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],
+    "radtran_radiate_resident": [_vp, _ip, _ip, _err],
+    "radtran_synchronize": [_vp, _err],
+    "radtran_flux_device_ptr": [_vp, _vpp, _ip],
+    "radtran_set_bin_shard": [_vp, _ip, _ip, _err],
+    "radtran_finish_reduced": [_vp, _err],
+    "radtran_stream_get": [_vp, _vpp],
+    "radtran_profile_set": [_vp, _ip],
+    "radtran_kernel_time_get": [_vp, _ip, _dp, _ip, _err],
+    "radtran_profile_reset": [_vp],
+    "radtran_algorithmic_bytes": [_vp, _dp, _dp, _dp, _dp, _err],
+    "radtran_opr_get": [_vp, _dp, _dp, _dp, _dp, _err],
+    "radtran_set_bolometric_flux_wrapper": [_vp, _dp],
+    "radtran_bolometric_flux_wrapper": [_vp, _dp],
+    "radtran_skin_temperature_wrapper": [_vp, _dp, _dp],
+    "radtran_equilibrium_temperature_wrapper": [_vp, _dp, _dp],
+    "radtran_zenith_u_get_size": [_vp, _ip],
+    "radtran_zenith_u_get": [_vp, _ip, _dp],
+    "radtran_zenith_u_set": [_vp, _ip, _dp],
+    "radtran_zenith_weights_get": [_vp, _ip, _dp],
+    "radtran_zenith_weights_set": [_vp, _ip, _dp],
+    "radtran_surface_albedo_get_size": [_vp, _ip],
+    "radtran_surface_albedo_get": [_vp, _ip, _dp],
+    "radtran_surface_albedo_set": [_vp, _ip, _dp],
+    "radtran_surface_emissivity_get_size": [_vp, _ip],
+    "radtran_surface_emissivity_get": [_vp, _ip, _dp],
+    "radtran_surface_emissivity_set": [_vp, _ip, _dp],
+    "radtran_has_hard_surface_get": [_vp, _ip],
+    "radtran_has_hard_surface_set": [_vp, _ip],
+    "radtran_photon_scale_factor_get": [_vp, _dp],
+    "radtran_photon_scale_factor_set": [_vp, _dp],
+    "radtran_ir_tau_min_get": [_vp, _dp],
+    "radtran_ir_tau_min_set": [_vp, _dp],
+    "radtran_diurnal_fac_get": [_vp, _dp],
+    "radtran_diurnal_fac_set": [_vp, _dp],
+    "radtran_ir_get": [_vp, _vpp],
+    "radtran_sol_get": [_vp, _vpp],
+    "radtran_wrk_ir_get": [_vp, _vpp],
+    "radtran_wrk_sol_get": [_vp, _vpp],
+    "radtran_f_total_get_size": [_vp, _ip],
+    "radtran_f_total_get": [_vp, _ip, _dp],
+    "radtran_photons_sol_get_size": [_vp, _ip],
+    "radtran_photons_sol_get": [_vp, _ip, _dp],
+    "climaradtranwrk_fup_a_get_size": [_vp, _ip, _ip],
+    "climaradtranwrk_fup_a_get": [_vp, _ip, _ip, _dp],
+    "climaradtranwrk_fdn_a_get_size": [_vp, _ip, _ip],
+    "climaradtranwrk_fdn_a_get": [_vp, _ip, _ip, _dp],
+    "climaradtranwrk_fup_n_get_size": [_vp, _ip],
+    "climaradtranwrk_fup_n_get": [_vp, _ip, _dp],
+    "climaradtranwrk_fdn_n_get_size": [_vp, _ip],
+    "climaradtranwrk_fdn_n_get": [_vp, _ip, _dp],
+    "climaradtranwrk_amean_get_size": [_vp, _ip, _ip],
+    "climaradtranwrk_amean_get": [_vp, _ip, _ip, _dp],
+    "climaradtranwrk_tau_band_get_size": [_vp, _ip, _ip],
+    "climaradtranwrk_tau_band_get": [_vp, _ip, _ip, _dp],
+    "rtchannel_wavl_get_size": [_vp, _ip],
+    "rtchannel_wavl_get": [_vp, _ip, _dp],
+    "rtchannel_freq_get_size": [_vp, _ip],
+    "rtchannel_freq_get": [_vp, _ip, _dp],
+}
+
+_lib = None
+
+
+def load():
+    """Load libclima_radtran_hip.so; raise loudly when it is absent (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "clima_amd: HIP extension %s is missing. Build it with "
+                "`python -m clima_amd.build` (hipcc, gfx950); there is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.argtypes = argtypes
+            fn.restype = None
+        _lib = L
+    return _lib

@@ -1,0 +1,346 @@
+"""Python mirror of Clima's `Radtran` (clima/cython/Radtran.pyx, ClimaRadtranWrk.pyx,
+RTChannel.pyx) over the HIP C ABI.  Same attribute names, argument meaning and error
+behaviour (`ClimaException` carrying the reference's message text).
+
+The reference's Python layer reaches `Radtran%radiate` only through `AdiabatClimate`
+(`c.rad`); here the `Radtran` object itself is constructible from a table set because the
+HDF5/YAML loaders are outside the hot path (SURVEY.md 8(f) "next #1").
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+
+_dp = C.POINTER(C.c_double)
+
+
+class ClimaException(Exception):
+    """clima/cython/_clima.pyx: raised with the Fortran `err` text."""
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(v):
+    return C.byref(C.c_int(int(v)))
+
+
+def _f(v):
+    return C.byref(C.c_double(float(v)))
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _fo(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+class RTChannel:
+    """clima/cython/RTChannel.pyx"""
+
+    def __init__(self, L, ptr):
+        self._L, self._ptr = L, ptr
+
+    def _vec(self, name):
+        n = C.c_int()
+        getattr(self._L, "rtchannel_%s_get_size" % name)(self._ptr, C.byref(n))
+        arr = np.empty(n.value, np.double)
+        getattr(self._L, "rtchannel_%s_get" % name)(self._ptr, C.byref(n), _d(arr))
+        return arr
+
+    @property
+    def wavl(self):
+        "ndarray[double,ndim=1]. Edges of the wavelength bins (nm)."
+        return self._vec("wavl")
+
+    @property
+    def freq(self):
+        "ndarray[double,ndim=1]. Edges of the bins in frequency (1/s)."
+        return self._vec("freq")
+
+
+class ClimaRadtranWrk:
+    """clima/cython/ClimaRadtranWrk.pyx: arrays are copied out, Fortran order, index 0 =
+    ground level, index nz = top of the atmosphere."""
+
+    def __init__(self, L, ptr):
+        self._L, self._ptr = L, ptr
+
+    def _mat(self, name):
+        d1, d2 = C.c_int(), C.c_int()
+        getattr(self._L, "climaradtranwrk_%s_get_size" % name)(self._ptr, C.byref(d1), C.byref(d2))
+        arr = np.empty((d1.value, d2.value), np.double, order="F")
+        getattr(self._L, "climaradtranwrk_%s_get" % name)(self._ptr, C.byref(d1), C.byref(d2), _d(arr))
+        return arr
+
+    def _vec(self, name):
+        d1 = C.c_int()
+        getattr(self._L, "climaradtranwrk_%s_get_size" % name)(self._ptr, C.byref(d1))
+        arr = np.empty(d1.value, np.double)
+        getattr(self._L, "climaradtranwrk_%s_get" % name)(self._ptr, C.byref(d1), _d(arr))
+        return arr
+
+    fup_a = property(lambda self: self._mat("fup_a"), doc="(nz+1,nw) mW/m^2/Hz upward flux per bin")
+    fdn_a = property(lambda self: self._mat("fdn_a"), doc="(nz+1,nw) mW/m^2/Hz downward flux per bin")
+    amean = property(lambda self: self._mat("amean"), doc="(nz+1,nw) mean intensity, photons/cm^2/s (solar)")
+    tau_band = property(lambda self: self._mat("tau_band"), doc="(nz,nw) band optical thickness")
+    fup_n = property(lambda self: self._vec("fup_n"), doc="(nz+1) mW/m^2 upward flux")
+    fdn_n = property(lambda self: self._vec("fdn_n"), doc="(nz+1) mW/m^2 downward flux")
+
+
+class Radtran:
+    """`type Radtran` (src/radtran/clima_radtran.f90:31-85) on the MI355X."""
+
+    def __init__(self, tables, nz, num_zenith_angles, surface_albedo):
+        """Equivalent of `Radtran(species, particles, settings, star, num_zenith_angles,
+        surface_albedo, nz, datadir)` (clima_radtran.f90:128-219) with the loaded tables
+        handed over as a `clima_amd.synthetic.TableSet`-shaped object."""
+        L = _lib.load()
+        self._L = L
+        self._ptr = C.c_void_p()
+        L.allocate_radtran(C.byref(self._ptr))
+        self._err = C.create_string_buffer(_lib.ERR_LEN + 1)
+        t = tables
+        self.nz = int(nz)
+        self.ng = t.nsp  # number of gases, as Radtran%ng
+        self.np = t.np_
+        self.species_names = list(t.species_names)
+        self.particle_names = list(t.particle_names)
+        wavl = _c(t.wavl)
+        L.radtran_create_begin(self._ptr, _i(nz), _i(t.nsp), _i(t.np_), _i(t.nw), _d(wavl), self._err)
+        self._check()
+        for k in t.ktables:
+            w, lp, tt, kk = _c(k["weights"]), _c(k["log10P"]), _c(k["temp"]), _c(k["log10k"])
+            L.radtran_add_ktable(self._ptr, _i(k["sp_ind"] + 1), _i(len(w)), _d(w), _i(len(lp)), _d(lp),
+                                 _i(len(tt)), _d(tt), _d(kk), self._err)
+            self._check()
+        for x in t.xsections:
+            temp = x.get("temp")
+            tt = _c(temp if temp is not None else np.zeros(1))
+            da = _c(x["data"])
+            L.radtran_add_xsection(self._ptr, _i(x["xs_type"]), _i(x["dim"]), _i(x["sp1"] + 1),
+                                   _i(x.get("sp2", -1) + 1), _i(0 if temp is None else len(temp)), _d(tt), _d(da),
+                                   self._err)
+            self._check()
+        if t.continuum is not None:
+            c = t.continuum
+            tt, a, b = _c(c["temp"]), _c(c["log10_H2O"]), _c(c["log10_foreign"])
+            L.radtran_set_water_continuum(self._ptr, _i(c["LH2O"] + 1), _i(len(tt)), _d(tt), _d(a), _d(b), self._err)
+            self._check()
+        for p in t.particles:
+            r, a, b, g = _c(p["radii"]), _c(p["w0"]), _c(p["qext"]), _c(p["gt"])
+            L.radtran_add_particle(self._ptr, _i(p["p_ind"] + 1), _i(len(r)), _d(r), _d(a), _d(b), _d(g), self._err)
+            self._check()
+        iw, sw = _c(t.ir_wavl), _c(t.sol_wavl)
+        L.radtran_set_channels(self._ptr, _i(len(iw)), _d(iw), _i(len(sw)), _d(sw), self._err)
+        self._check()
+        ps = _c(t.photons_sol)
+        L.radtran_set_photons_sol(self._ptr, _i(len(ps)), _d(ps), self._err)
+        self._check()
+        L.radtran_create_end(self._ptr, _i(num_zenith_angles), _f(surface_albedo), self._err)
+        self._check()
+        self.nw = t.nw
+        self.ngauss = t.ng
+
+    def __del__(self):
+        if getattr(self, "_ptr", None) is not None and self._ptr.value:
+            self._L.deallocate_radtran(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def _check(self):
+        msg = self._err.value
+        if len(msg.strip()) > 0:
+            raise ClimaException(msg.decode("utf-8").strip())
+
+    # ------------------------------------------------------------------ the path
+    def _column_args(self, T, P, densities, dz, pdensities, radii):
+        T, P, dz = _c(T), _c(P), _c(dz)
+        densities = _fo(densities)
+        if densities.ndim != 2:
+            raise ClimaException('"densities" has the wrong input dimension.')
+        has_p = pdensities is not None or radii is not None
+        if has_p and (pdensities is None or radii is None):
+            raise ClimaException("Both pdensities and radii must be arguments.")
+        if has_p:
+            pdensities, radii = _fo(pdensities), _fo(radii)
+            if pdensities.shape != radii.shape:
+                raise ClimaException('"radii" has the wrong input dimension.')
+            p1, p2 = pdensities.shape if pdensities.ndim == 2 else (pdensities.shape[0], 1)
+            pd, ra = _d(pdensities), _d(radii)
+        else:
+            p1 = p2 = 0
+            pd = ra = None
+        keep = (T, P, dz, densities, pdensities, radii)
+        args = (_i(len(T)), _d(T), _i(len(P)), _d(P), _i(densities.shape[0]), _i(densities.shape[1]), _d(densities),
+                _i(len(dz)), _d(dz), _i(1 if has_p else 0), _i(p1), _i(p2), pd, ra)
+        return keep, args
+
+    def radiate(self, T_surface, T, P, densities, dz, pdensities=None, radii=None, compute_solar=True,
+                compute_opacity=True):
+        """Radtran%radiate (clima_radtran.f90:221-318).  T (K), P (bar), densities (nz,ng)
+        molecules/cm^3, dz (cm); fills wrk_ir, wrk_sol and f_total."""
+        keep, a = self._column_args(T, P, densities, dz, pdensities, radii)
+        self._L.radtran_radiate_wrapper(self._ptr, _f(T_surface), *a, _i(compute_solar), _i(compute_opacity),
+                                        self._err)
+        del keep
+        self._check()
+
+    def TOA_fluxes(self, T_surface, T, P, densities, dz, pdensities=None, radii=None, compute_solar=True,
+                   compute_opacity=True):
+        """Radtran%TOA_fluxes (clima_radtran.f90:320-342) -> (ISR, OLR) in mW/m^2."""
+        keep, a = self._column_args(T, P, densities, dz, pdensities, radii)
+        isr, olr = C.c_double(), C.c_double()
+        self._L.radtran_toa_fluxes_wrapper(self._ptr, _f(T_surface), *a, _i(compute_solar), _i(compute_opacity),
+                                           C.byref(isr), C.byref(olr), self._err)
+        del keep
+        self._check()
+        return isr.value, olr.value
+
+    def apply_radiation_enhancement(self, rad_enhancement):
+        self._L.radtran_apply_radiation_enhancement(self._ptr, _f(rad_enhancement))
+
+    # ---- HBM-resident form (bench / batched callers)
+    def upload_column(self, T_surface, T, P, densities, dz, pdensities=None, radii=None):
+        T, P, dz, densities = _c(T), _c(P), _c(dz), _fo(densities)
+        if len(T) != self.nz or len(P) != self.nz or len(dz) != self.nz or densities.shape != (self.nz, self.ng):
+            raise ClimaException('"densities" has the wrong input dimension.')
+        pd = ra = None
+        if pdensities is not None:
+            pdensities, radii = _fo(pdensities), _fo(radii)
+            pd, ra = _d(pdensities), _d(radii)
+        self._L.radtran_upload_column(self._ptr, _f(T_surface), _d(T), _d(P), _d(densities), _d(dz), pd, ra, self._err)
+        self._check()
+
+    def radiate_resident(self, compute_solar=True, compute_opacity=True):
+        self._L.radtran_radiate_resident(self._ptr, _i(compute_solar), _i(compute_opacity), self._err)
+        self._check()
+
+    def synchronize(self):
+        self._L.radtran_synchronize(self._ptr, self._err)
+        self._check()
+
+    def set_bin_shard(self, rank, world):
+        self._L.radtran_set_bin_shard(self._ptr, _i(rank), _i(world), self._err)
+        self._check()
+
+    def finish_reduced(self):
+        self._L.radtran_finish_reduced(self._ptr, self._err)
+        self._check()
+
+    def flux_device_ptr(self):
+        p, n = C.c_void_p(), C.c_int()
+        self._L.radtran_flux_device_ptr(self._ptr, C.byref(p), C.byref(n))
+        return p.value, n.value
+
+    def stream(self):
+        p = C.c_void_p()
+        self._L.radtran_stream_get(self._ptr, C.byref(p))
+        return p.value
+
+    def profile(self, enable=True):
+        self._L.radtran_profile_set(self._ptr, _i(1 if enable else 0))
+
+    def profile_reset(self):
+        self._L.radtran_profile_reset(self._ptr)
+
+    def kernel_time(self, kernel_id):
+        ms, n = C.c_double(), C.c_int()
+        self._L.radtran_kernel_time_get(self._ptr, _i(kernel_id), C.byref(ms), C.byref(n), self._err)
+        self._check()
+        return ms.value, n.value
+
+    def algorithmic_bytes(self):
+        a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self._L.radtran_algorithmic_bytes(self._ptr, C.byref(a), C.byref(b), C.byref(c), C.byref(d), self._err)
+        self._check()
+        return dict(tables_distinct=a.value, input=b.value, output=c.value, tables_full=d.value)
+
+    def opr(self):
+        """OpticalPropertiesResult: tau,w0 (nz,ngauss,nw), g,tau_band (nz,nw); TOA-first."""
+        nz, ng, nw = self.nz, self.ngauss, self.nw
+        tau = np.empty((nz, ng, nw), order="F")
+        w0 = np.empty((nz, ng, nw), order="F")
+        g = np.empty((nz, nw), order="F")
+        tb = np.empty((nz, nw), order="F")
+        self._L.radtran_opr_get(self._ptr, _d(tau), _d(w0), _d(g), _d(tb), self._err)
+        self._check()
+        return tau, w0, g, tb
+
+    # ------------------------------------------------------------------ Radtran.pyx surface
+    def set_bolometric_flux(self, flux):
+        self._L.radtran_set_bolometric_flux_wrapper(self._ptr, _f(flux))
+
+    def bolometric_flux(self):
+        v = C.c_double()
+        self._L.radtran_bolometric_flux_wrapper(self._ptr, C.byref(v))
+        return v.value
+
+    def skin_temperature(self, bond_albedo):
+        v = C.c_double()
+        self._L.radtran_skin_temperature_wrapper(self._ptr, _f(bond_albedo), C.byref(v))
+        return v.value
+
+    def equilibrium_temperature(self, bond_albedo):
+        v = C.c_double()
+        self._L.radtran_equilibrium_temperature_wrapper(self._ptr, _f(bond_albedo), C.byref(v))
+        return v.value
+
+    def _vec_get(self, name, size_name=None):
+        n = C.c_int()
+        getattr(self._L, "radtran_%s_get_size" % (size_name or name))(self._ptr, C.byref(n))
+        arr = np.empty(n.value, np.double)
+        getattr(self._L, "radtran_%s_get" % name)(self._ptr, C.byref(n), _d(arr))
+        return arr
+
+    def _vec_set(self, name, arr, size_name=None):
+        arr = _c(arr)
+        n = C.c_int()
+        getattr(self._L, "radtran_%s_get_size" % (size_name or name))(self._ptr, C.byref(n))
+        if arr.ndim != 1 or arr.shape[0] != n.value:
+            raise ClimaException('"%s" is the wrong size' % name)
+        getattr(self._L, "radtran_%s_set" % name)(self._ptr, C.byref(n), _d(arr))
+
+    zenith_u = property(lambda s: s._vec_get("zenith_u"), lambda s, a: s._vec_set("zenith_u", a),
+                        doc="cosine of the zenith angles")
+    zenith_weights = property(lambda s: s._vec_get("zenith_weights", "zenith_u"),
+                              lambda s, a: s._vec_set("zenith_weights", a, "zenith_u"))
+    surface_albedo = property(lambda s: s._vec_get("surface_albedo"), lambda s, a: s._vec_set("surface_albedo", a),
+                              doc="surface albedo in each solar bin")
+    surface_emissivity = property(lambda s: s._vec_get("surface_emissivity"),
+                                  lambda s, a: s._vec_set("surface_emissivity", a),
+                                  doc="surface emissivity in each IR bin")
+    photons_sol = property(lambda s: s._vec_get("photons_sol"))
+    f_total = property(lambda s: s._vec_get("f_total"))
+
+    def _scalar(name, ctype):
+        def get(self):
+            v = ctype()
+            getattr(self._L, "radtran_%s_get" % name)(self._ptr, C.byref(v))
+            return bool(v.value) if ctype is C.c_int else v.value
+
+        def set_(self, val):
+            getattr(self._L, "radtran_%s_set" % name)(self._ptr, C.byref(ctype(int(val) if ctype is C.c_int else float(val))))
+
+        return property(get, set_)
+
+    has_hard_surface = _scalar("has_hard_surface", C.c_int)
+    photon_scale_factor = _scalar("photon_scale_factor", C.c_double)
+    ir_tau_min = _scalar("ir_tau_min", C.c_double)
+    diurnal_fac = _scalar("diurnal_fac", C.c_double)
+    del _scalar
+
+    def _sub(self, name, cls):
+        p = C.c_void_p()
+        getattr(self._L, "radtran_%s_get" % name)(self._ptr, C.byref(p))
+        obj = cls(self._L, p)
+        obj._parent = self  # keep the handle alive while the borrowed pointer is in use
+        return obj
+
+    ir = property(lambda s: s._sub("ir", RTChannel), doc="RTChannel of the IR bins")
+    sol = property(lambda s: s._sub("sol", RTChannel), doc="RTChannel of the solar bins")
+    wrk_ir = property(lambda s: s._sub("wrk_ir", ClimaRadtranWrk), doc="IR results")
+    wrk_sol = property(lambda s: s._sub("wrk_sol", ClimaRadtranWrk), doc="solar results")

@@ -1,0 +1,199 @@
+/*
+ * clima_radtran_hip.h -- C ABI of the MI355X-native Radtran hot path.
+ *
+ * Drop-in boundary for Clima's `type Radtran` (src/radtran/clima_radtran.f90:31-85) and the
+ * bind(c) shim above it (clima/fortran/Radtran.f90, ClimaRadtranWrk.f90, RTChannel.f90).
+ * Conventions are the reference's (clima/fortran/clima_c_api.f90:5, AdiabatClimate.f90:169-190):
+ *   - handles are opaque `void*` passed BY VALUE; every scalar is passed BY REFERENCE;
+ *   - arrays are bare pointers with explicit extents; 2-D arrays are column-major;
+ *   - errors: `char err[CLIMA_ERR_LEN+1]`, err[0]==0 <=> success; message text is API;
+ *   - species / particle indices are 1-based (Fortran `sp_ind`, `p_ind`);
+ *   - the object is not thread-safe; calls on one handle are serialised on its HIP stream.
+ * No torch / C++ types cross this boundary.  All symbols are implemented by
+ * clima_amd/csrc/libclima_radtran_hip.so; there is no CPU fallback: every entry point
+ * that needs the GPU fails with a message in `err` when HIP is unavailable.
+ */
+#ifndef CLIMA_RADTRAN_HIP_H
+#define CLIMA_RADTRAN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLIMA_ERR_LEN 1024
+
+/* Xsection kinds: enum at src/radtran/clima_radtran_types.f90:40-42 */
+#define CLIMA_XS_CIA 0
+#define CLIMA_XS_RAYLEIGH 1
+#define CLIMA_XS_ABSORPTION 2
+#define CLIMA_XS_PHOTOLYSIS 3
+
+/* ------------------------------------------------------------------------------------
+ * Construction.  Replaces create_Radtran_2 (src/radtran/clima_radtran.f90:128-219): the
+ * HDF5/YAML loaders (clima_radtran_types_create.f90) stay on the host side of the
+ * boundary and hand over the tables they produce.
+ * ---------------------------------------------------------------------------------- */
+
+/* allocate / free an empty handle (pattern of allocate_adiabatclimate /
+ * deallocate_adiabatclimate, clima/fortran/AdiabatClimate.f90:7-22) */
+void allocate_radtran(void **ptr);
+void deallocate_radtran(void *ptr);
+
+/* nz layers, nsp gases (rad%ng), np particles, nw opacity bins, wavl[nw+1] nm ascending
+ * (OpticalProperties%wavl, clima_radtran_types.f90:96-99) */
+void radtran_create_begin(void *ptr, const int *nz, const int *nsp, const int *np,
+                          const int *nw, const double *wavl, char *err);
+/* Ktable (clima_radtran_types.f90:23-38).  log10k is the on-disk array
+ * log10k(ngauss,npress,ntemp,nwav), column-major (types_create.f90:1349-1358). */
+void radtran_add_ktable(void *ptr, const int *sp_ind, const int *ngauss,
+                        const double *weights, const int *npress, const double *log10P,
+                        const int *ntemp, const double *temp, const double *log10k,
+                        char *err);
+/* Xsection (clima_radtran_types.f90:44-55) after regridding to the bin grid
+ * (types_create.f90:1171-1257): dim 0 -> data(nw) = xs; dim 1 -> data(ntemp,nw) = log10 xs.
+ * sp_ind2 is used by CIA only. */
+void radtran_add_xsection(void *ptr, const int *xs_type, const int *dim, const int *sp_ind1,
+                          const int *sp_ind2, const int *ntemp, const double *temp,
+                          const double *data, char *err);
+/* WaterContinuum (clima_radtran_types.f90:68-77): log10_xs_*(ntemp,nw) */
+void radtran_set_water_continuum(void *ptr, const int *LH2O, const int *ntemp,
+                                 const double *temp, const double *log10_xs_H2O,
+                                 const double *log10_xs_foreign, char *err);
+/* ParticleXsection (clima_radtran_types.f90:57-66): w0,qext,gt (nrad,nw) */
+void radtran_add_particle(void *ptr, const int *p_ind, const int *nrad, const double *radii,
+                          const double *w0, const double *qext, const double *gt, char *err);
+/* RTChannel edges in nm; index ranges resolved like create_RTChannel
+ * (types_create.f90:226-270), same error text on mismatch. */
+void radtran_set_channels(void *ptr, const int *n_ir_edges, const double *ir_wavl,
+                          const int *n_sol_edges, const double *sol_wavl, char *err);
+/* rad%photons_sol(sol%nw), mW/m^2/Hz -- output of read_stellar_flux (types_create.f90:9-78) */
+void radtran_set_photons_sol(void *ptr, const int *n, const double *photons_sol, char *err);
+/* zenith angles (Gauss-Legendre, clima_eqns.f90:26-41), albedo/emissivity defaults,
+ * result arrays (clima_radtran.f90:162-217); uploads the tables to HBM. */
+void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *surface_albedo,
+                        char *err);
+
+/* ------------------------------------------------------------------------------------
+ * The path.  The reference exposes no C symbol for Radtran%radiate itself (it is reached
+ * through adiabatclimate_* only); these two are the ones a maintainer binds instead.
+ * ---------------------------------------------------------------------------------- */
+
+/* Radtran%radiate (clima_radtran.f90:221-318).  densities(dim1_d,dim2_d),
+ * pdensities/radii(dim1_p,dim2_p) column-major; pass has_particles=0 and NULLs when the
+ * optional arguments are absent.  Dimension errors reproduce check_inputs (:417-491). */
+void radtran_radiate_wrapper(void *ptr, const double *T_surface, const int *dim_T,
+                             const double *T, const int *dim_P, const double *P,
+                             const int *dim1_d, const int *dim2_d, const double *densities,
+                             const int *dim_dz, const double *dz, const int *has_particles,
+                             const int *dim1_p, const int *dim2_p, const double *pdensities,
+                             const double *radii, const int *compute_solar,
+                             const int *compute_opacity, char *err);
+/* Radtran%TOA_fluxes (clima_radtran.f90:320-342) */
+void radtran_toa_fluxes_wrapper(void *ptr, const double *T_surface, const int *dim_T,
+                                const double *T, const int *dim_P, const double *P,
+                                const int *dim1_d, const int *dim2_d, const double *densities,
+                                const int *dim_dz, const double *dz, const int *has_particles,
+                                const int *dim1_p, const int *dim2_p, const double *pdensities,
+                                const double *radii, const int *compute_solar,
+                                const int *compute_opacity, double *ISR, double *OLR,
+                                char *err);
+/* Radtran%apply_radiation_enhancement (clima_radtran.f90:402-411) */
+void radtran_apply_radiation_enhancement(void *ptr, const double *rad_enhancement);
+
+/* ---- HBM-resident form of the same call (no PCIe inside the timed region) ----
+ * upload_column copies the column into the handle's device buffers; radiate_resident
+ * enqueues opacity + IR + solar + integration on the handle's stream and returns without
+ * a host sync; synchronize waits and surfaces device-side failures (e.g. the particle
+ * radius clamp of interpolate_Particle, clima_radtran_types.f90:973-976). */
+void radtran_upload_column(void *ptr, const double *T_surface, const double *T, const double *P,
+                           const double *densities, const double *dz, const double *pdensities,
+                           const double *radii, char *err);
+void radtran_radiate_resident(void *ptr, const int *compute_solar, const int *compute_opacity,
+                              char *err);
+void radtran_synchronize(void *ptr, char *err);
+/* device pointer to the packed level fluxes [ir_up, ir_dn, sol_up, sol_dn][nz+1] (f64):
+ * the buffer a bin-sharded run all-reduces over RCCL. */
+void radtran_flux_device_ptr(void *ptr, void **dptr, int *count);
+/* restrict this handle to opacity bins of shard `rank` out of `world` (work-balanced
+ * contiguous ranges; rank 0-based).  world=1 restores the full grid. */
+void radtran_set_bin_shard(void *ptr, const int *rank, const int *world, char *err);
+/* after an external all-reduce of the flux buffer: recompute f_total on the device */
+void radtran_finish_reduced(void *ptr, char *err);
+/* HIP stream the handle launches on (for callers that order other work against it) */
+void radtran_stream_get(void *ptr, void **stream);
+/* per-kernel device time (HIP events on the handle's stream).  enable!=0 records events
+ * around every kernel; kernel_time_get returns accumulated ms and launch count for
+ * kernel id (0 prep, 1 opacity, 2 twostream, 3 integrate) and resets nothing. */
+void radtran_profile_set(void *ptr, const int *enable);
+void radtran_kernel_time_get(void *ptr, const int *kernel_id, double *ms_total, int *launches,
+                             char *err);
+void radtran_profile_reset(void *ptr);
+/* algorithmic-byte accounting of SURVEY.md 8(d) for the last uploaded column */
+void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double *bytes_in,
+                               double *bytes_out, double *bytes_tables_full, char *err);
+
+/* OpticalPropertiesResult (clima_radtran_types.f90:242-247), for parity checks:
+ * tau,w0 (nz,ngauss,nw) and g,tau_band (nz,nw), column-major, TOA-first. */
+void radtran_opr_get(void *ptr, double *tau, double *w0, double *g, double *tau_band, char *err);
+
+/* ------------------------------------------------------------------------------------
+ * Getters / setters with the reference's names and signatures
+ * (clima/fortran/Radtran.f90:3-299).
+ * ---------------------------------------------------------------------------------- */
+void radtran_set_bolometric_flux_wrapper(void *ptr, const double *flux);             /* :3  */
+void radtran_bolometric_flux_wrapper(void *ptr, double *flux);                       /* :12 */
+void radtran_skin_temperature_wrapper(void *ptr, const double *bond_albedo, double *T_skin); /* :21 */
+void radtran_equilibrium_temperature_wrapper(void *ptr, const double *bond_albedo, double *T_eq); /* :31 */
+void radtran_zenith_u_get_size(void *ptr, int *dim1);                                /* :124 */
+void radtran_zenith_u_get(void *ptr, const int *dim1, double *arr);                  /* :133 */
+void radtran_zenith_u_set(void *ptr, const int *dim1, const double *arr);            /* :143 */
+void radtran_zenith_weights_get(void *ptr, const int *dim1, double *arr);            /* field :53 */
+void radtran_zenith_weights_set(void *ptr, const int *dim1, const double *arr);
+void radtran_surface_albedo_get_size(void *ptr, int *dim1);                          /* :153 */
+void radtran_surface_albedo_get(void *ptr, const int *dim1, double *arr);            /* :162 */
+void radtran_surface_albedo_set(void *ptr, const int *dim1, const double *arr);      /* :172 */
+void radtran_surface_emissivity_get_size(void *ptr, int *dim1);                      /* :182 */
+void radtran_surface_emissivity_get(void *ptr, const int *dim1, double *arr);        /* :191 */
+void radtran_surface_emissivity_set(void *ptr, const int *dim1, const double *arr);  /* :201 */
+void radtran_has_hard_surface_get(void *ptr, int *val);                              /* :211 */
+void radtran_has_hard_surface_set(void *ptr, const int *val);                        /* :220 */
+void radtran_photon_scale_factor_get(void *ptr, double *val);                        /* :229 */
+void radtran_photon_scale_factor_set(void *ptr, const double *val);                  /* :238 */
+void radtran_ir_tau_min_get(void *ptr, double *val);                                 /* :247 */
+void radtran_ir_tau_min_set(void *ptr, const double *val);                           /* :256 */
+void radtran_diurnal_fac_get(void *ptr, double *val);                                /* field :51 */
+void radtran_diurnal_fac_set(void *ptr, const double *val);
+void radtran_ir_get(void *ptr, void **ptr1);                                         /* :265 */
+void radtran_sol_get(void *ptr, void **ptr1);                                        /* :274 */
+void radtran_wrk_ir_get(void *ptr, void **ptr1);                                     /* :283 */
+void radtran_wrk_sol_get(void *ptr, void **ptr1);                                    /* :292 */
+void radtran_f_total_get_size(void *ptr, int *dim1);                                 /* field :72 */
+void radtran_f_total_get(void *ptr, const int *dim1, double *arr);
+void radtran_photons_sol_get_size(void *ptr, int *dim1);                             /* field :65 */
+void radtran_photons_sol_get(void *ptr, const int *dim1, double *arr);
+
+/* ClimaRadtranWrk (clima/fortran/ClimaRadtranWrk.f90:7-123); ptr from radtran_wrk_*_get.
+ * Getters copy device results out on first use after a radiate (lazy D2H). */
+void climaradtranwrk_fup_a_get_size(void *ptr, int *dim1, int *dim2);
+void climaradtranwrk_fup_a_get(void *ptr, const int *dim1, const int *dim2, double *arr);
+void climaradtranwrk_fdn_a_get_size(void *ptr, int *dim1, int *dim2);
+void climaradtranwrk_fdn_a_get(void *ptr, const int *dim1, const int *dim2, double *arr);
+void climaradtranwrk_fup_n_get_size(void *ptr, int *dim1);
+void climaradtranwrk_fup_n_get(void *ptr, const int *dim1, double *arr);
+void climaradtranwrk_fdn_n_get_size(void *ptr, int *dim1);
+void climaradtranwrk_fdn_n_get(void *ptr, const int *dim1, double *arr);
+void climaradtranwrk_amean_get_size(void *ptr, int *dim1, int *dim2);
+void climaradtranwrk_amean_get(void *ptr, const int *dim1, const int *dim2, double *arr);
+void climaradtranwrk_tau_band_get_size(void *ptr, int *dim1, int *dim2);
+void climaradtranwrk_tau_band_get(void *ptr, const int *dim1, const int *dim2, double *arr);
+
+/* RTChannel (clima/fortran/RTChannel.f90:3-38); ptr from radtran_ir_get / radtran_sol_get */
+void rtchannel_wavl_get_size(void *ptr, int *dim1);
+void rtchannel_wavl_get(void *ptr, const int *dim1, double *arr);
+void rtchannel_freq_get_size(void *ptr, int *dim1);
+void rtchannel_freq_get(void *ptr, const int *dim1, double *arr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
