@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the radiate() hot path (BASELINE.json: `radiate() calls/sec`, 200-layer
+ModernEarth column, full solar+IR correlated-k bin grid).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE full `Radtran%radiate` call -- opacity assembly + IR + solar two-stream +
+spectral integration -- on the ModernEarth column of tests/test_radtran.f90 (config 2:
+nz=200, nw=1000 opacity bins (600 IR / 600 solar), 8 g-points, 8 zenith angles, 5
+k-distribution species, synthetic tables: SURVEY.md 8(d)).  Inputs (tables and the
+column) are resident in HBM before the timed region starts; the PCIe-inclusive rate is
+reported separately in DESIGN.md.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the spectral bins of the SAME
+call are sharded over the ranks (work-balanced contiguous ranges) and every step ends with
+one RCCL all-reduce of the 4*(nz+1) partial level fluxes -- strong scaling of one call.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP
+events on the stream it is launched on; `cpu_baseline` is the oracle (a port of the
+reference's algorithm, OpenMP over bins exactly like the reference) timed on this box's
+host cores on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+KERNELS = ["prep", "opacity", "twostream", "integrate"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nz", type=int, default=200)
+    ap.add_argument("--nzen", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the Radtran hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+
+    nz, nzen = args.nz, args.nzen
+    tables = S.modern_earth_tables()
+    col = S.modern_earth_column(nz)
+    rad = Radtran(tables, nz, nzen, 0.15)  # tests/test_radtran.f90:35-38
+    if world > 1:
+        rad.set_bin_shard(rank, world)
+    rad.upload_column(*col.args())
+    flux = rad.flux_tensor() if world > 1 else None
+
+    def step():
+        rad.radiate_resident()
+        if world > 1:
+            rad.synchronize()                 # library stream -> host
+            dist.all_reduce(flux)             # RCCL over xGMI: 4*(nz+1) doubles
+            torch.cuda.current_stream().synchronize()
+            rad.finish_reduced()              # f_total from the reduced fluxes
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        rad.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    rad.profile(True)
+    rad.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kt = [rad.kernel_time(i) for i in range(4)]
+    rad.profile(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    # ---- parity of what was just timed (rank 0 checks OLR against the oracle)
+    isr = float((flux[3 * (nz + 1) + nz] - flux[2 * (nz + 1) + nz]).item()) if world > 1 else None
+    if world > 1:
+        olr = -float((flux[1 * (nz + 1) + nz] - flux[0 * (nz + 1) + nz]).item())
+    else:
+        w_ir, w_sol = rad.wrk_ir, rad.wrk_sol
+        olr = -(w_ir.fdn_n[nz] - w_ir.fup_n[nz])
+        isr = w_sol.fdn_n[nz] - w_sol.fup_n[nz]
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = args.steps / dt
+        per_kernel_us = {k: (1e3 * ms / n if n else 0.0) for k, (ms, n) in zip(KERNELS, kt)}
+        dom = max(per_kernel_us, key=per_kernel_us.get)
+        ab = rad.algorithmic_bytes()
+        # algorithmic bytes of one call: distinct table nodes + inputs + outputs,
+        # prorated to the bins this rank owns
+        frac = rad.bin_shard()[1] / float(tables.nw)
+        b_alg = (ab["tables_distinct"] + ab["output"]) * frac + ab["input"]
+        dur = per_kernel_us[dom] * 1e-6
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": b_alg / dur / 1e9 if dur > 0 else 0.0,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (b_alg / dur / 1e9) / HBM_PEAK_GBS if dur > 0 else 0.0,
+                    "traffic": None, "algorithmic_bytes": b_alg, "kernel_us": per_kernel_us,
+                    "whole_call_frac": (b_alg / (dt / args.steps) / 1e9) / HBM_PEAK_GBS}
+        out = {"metric": "radiate() calls/sec", "value": value, "unit": "calls/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "ModernEarth column, one Radtran%%radiate call: nz=%d, nw=1000 "
+                                      "(600 IR + 600 solar bins), 8 g-points, %d zenith angles, nk=5; "
+                                      "config 2 of BASELINE.json" % (nz, nzen),
+                          "parallelism": ("bins sharded over %d GPUs + 1 all-reduce of %d f64" % (world, 4 * (nz + 1)))
+                          if world > 1 else "1 GPU"},
+               "olr_W_m2": olr / 1e3, "isr_W_m2": isr / 1e3, "roofline": roofline}
+        if not args.no_cpu_baseline and world == 1:
+            out.update(cpu_baseline(tables, col, nz, nzen, olr))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tables, col, nz, nzen, olr_gpu):
+    """The oracle (port of the reference algorithm, OpenMP over bins like the reference's
+    `!$omp parallel do`) on this box's host cores: whole radiate() calls of the same
+    workload, bounded to ~10-30 s."""
+    from oracle import oracle as O
+    O.build()
+    cores = min(os.cpu_count() or 1, 16)
+    O.lib().orc_set_num_threads(cores)
+    o = O.OracleRadtran(tables, nz, nzen, 0.15)
+    o.radiate(*col.args())  # warm (page-in, thread pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.radiate(*col.args())
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or n >= 40:
+            break
+    _, olr_o = o.TOA_fluxes(*col.args())
+    return {"cpu_baseline": {"value": n / el, "unit": "calls/s", "cores": cores, "kind": "port",
+                             "sample": "%d whole radiate() calls of the same workload (%.1f s)" % (n, el)},
+            "olr_rel_err_vs_cpu": abs(olr_gpu - olr_o) / abs(olr_o)}
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,31 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+FORTRAN_DIR = os.path.join(_HERE, "fortran")
+FORTRAN_DRIVER = os.path.join(FORTRAN_DIR, "radtran_driver")
+FLANG = os.environ.get("FLANG", "/opt/rocm/bin/amdflang")
+
+
+def build_fortran_shim(verbose=False):
+    """Compile the ISO_C_BINDING shim module and the test_radtran-shaped driver against the
+    HIP library (amdflang).  Returns the driver path, or None when no Fortran compiler."""
+    if not os.path.exists(FLANG):
+        if verbose:
+            print("amdflang not found: skipping the Fortran shim")
+        return None
+    srcs = [os.path.join(FORTRAN_DIR, "clima_radtran_hip.f90"), os.path.join(FORTRAN_DIR, "radtran_driver.f90")]
+    if os.path.exists(FORTRAN_DRIVER) and all(os.path.getmtime(FORTRAN_DRIVER) > os.path.getmtime(x)
+                                              for x in srcs + [LIB]):
+        return FORTRAN_DRIVER
+    cmd = [FLANG, "-O2", "-J", FORTRAN_DIR] + srcs + ["-o", FORTRAN_DRIVER, "-L" + CSRC, "-lclima_radtran_hip",
+                                                      "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return FORTRAN_DRIVER
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True,
           extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
+    build_fortran_shim(verbose=True)

@@ -20,6 +20,28 @@ namespace clima {
 // small device helpers
 // ------------------------------------------------------------------------------------
 
+// v_min_f64 / v_max_f64 without the sNaN-quieting canonicalisation hipcc wraps around
+// fmin/fmax (the operands here are never NaN)
+__device__ __forceinline__ double dmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double dmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (no scaling: |x| is O(1) where this is used)
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
 // ten2power, src/clima_eqns.f90:75-80
 __device__ __forceinline__ double ten2power(double y) { return exp(y * LN10); }
 
@@ -47,56 +69,71 @@ __device__ __forceinline__ int bracket(const double *xt, int n, double x) {
 }
 
 // ------------------------------------------------------------------------------------
-// k_prep: one block, threads stride over layers
+// k_prep: block 0 writes the per-layer column quantities; block b>=1 evaluates
+// interpolation slot b-1 for every layer (axis staged in LDS).  Every block re-derives
+// pair_reuse locally, so there is no inter-block dependency.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep(PrepParams p) {
+constexpr int PREP_AXIS_MAX = 1024;
+
+// source layer for interpolation: j, or j-1 when (j-1,j) is a reusable pair (types.f90:621-632)
+__device__ __forceinline__ int reuse_source(const PrepParams &p, int j) {
   const int nz = p.nz;
   const ColumnDev &c = p.col;
-  for (int j = threadIdx.x; j < nz; j += blockDim.x) {
-    c.log10P[j] = log10(c.P[j]);  // types.f90:605
-    double fc = 0.0;
-    for (int i = 0; i < p.nsp; i++) {  // :607-619
-      double col = c.dens[i * nz + j] * c.dz[j];
-      c.cols[i * nz + j] = col;
-      if (p.has_cont && i != p.LH2O) fc = fc + col;
+  if ((nz & 1) != 0 || (j & 1) == 0) return j;
+  const double tol = 1.0e-12;
+  bool ok = is_close(c.P[j], c.P[j - 1], tol) && is_close(c.T[j], c.T[j - 1], tol);
+  const double dzj = c.dz[j], dzm = c.dz[j - 1];
+  for (int i = 0; i < p.nsp; i++) ok = ok && is_close(c.dens[i * nz + j] * dzj, c.dens[i * nz + j - 1] * dzm, tol);
+  if (p.check_radii)
+    for (int i = 0; i < p.np; i++) ok = ok && is_close(c.radii[i * nz + j], c.radii[i * nz + j - 1], tol);
+  return ok ? j - 1 : j;
+}
+
+__global__ __launch_bounds__(256) void k_prep(PrepParams p) {
+  __shared__ double s_axis[PREP_AXIS_MAX];
+  const int nz = p.nz;
+  const ColumnDev &c = p.col;
+  if (blockIdx.x == 0) {
+    for (int j = threadIdx.x; j < nz; j += blockDim.x) {
+      c.log10P[j] = log10(c.P[j]);  // types.f90:605
+      double fc = 0.0;
+      for (int i = 0; i < p.nsp; i++) {  // :607-619
+        const double col = c.dens[i * nz + j] * c.dz[j];
+        c.cols[i * nz + j] = col;
+        if (p.has_cont && i != p.LH2O) fc = fc + col;
+      }
+      c.foreign_col[j] = fc;
+      c.src[j] = reuse_source(p, j);
     }
-    c.foreign_col[j] = fc;
+    return;
   }
-  __syncthreads();
-  // pair_reuse (:621-632): even nz only, second layer of each pair
-  for (int j = threadIdx.x; j < nz; j += blockDim.x) {
-    int src = j;
-    if ((nz & 1) == 0 && (j & 1) == 1) {
-      const double tol = 1.0e-12;
-      bool ok = is_close(c.P[j], c.P[j - 1], tol) && is_close(c.T[j], c.T[j - 1], tol);
-      for (int i = 0; i < p.nsp; i++) ok = ok && is_close(c.cols[i * nz + j], c.cols[i * nz + j - 1], tol);
-      if (p.check_radii)
-        for (int i = 0; i < p.np; i++) ok = ok && is_close(c.radii[i * nz + j], c.radii[i * nz + j - 1], tol);
-      if (ok) src = j - 1;
-    }
-    c.src[j] = src;
-  }
-  __syncthreads();
-  // interpolation brackets and weights per (slot, layer); reuse layers take their
+  // interpolation bracket and weight of one slot for every layer; reuse layers take their
   // source layer's inputs, which is what copying its interpolated value amounts to
   // (:652-653, :907-908, :933-935, :963-968)
-  for (int idx = threadIdx.x; idx < p.nslots * nz; idx += blockDim.x) {
-    const int s = idx / nz, j = idx - s * nz;
-    const SlotDev &sl = p.slots[s];
-    const int js = c.src[j];
+  const int s = blockIdx.x - 1;
+  const SlotDev &sl = p.slots[s];
+  const bool in_lds = sl.n <= PREP_AXIS_MAX;
+  if (in_lds)
+    for (int i = threadIdx.x; i < sl.n; i += blockDim.x) s_axis[i] = sl.axis[i];
+  __syncthreads();
+  const double *axis = in_lds ? s_axis : sl.axis;
+  for (int j = threadIdx.x; j < nz; j += blockDim.x) {
+    const int js = reuse_source(p, j);
     double x;
-    if (sl.source == 0) x = c.log10P[js];
+    if (sl.source == 0) x = log10(c.P[js]);
     else if (sl.source == 1) x = c.T[js];
     else x = c.radii[(sl.source - 2) * nz + js];
     if (sl.flag_clamp && (x < sl.lo || x > sl.hi)) atomicOr(c.err_flag, 1);
     x = fmin(fmax(x, sl.lo), sl.hi);  // :655-656, :910, :937, :974
-    const int i = bracket(sl.axis, sl.n, x);
-    c.ix[idx] = i;
-    c.q[idx] = (x - sl.axis[i]) / (sl.axis[i + 1] - sl.axis[i]);  // linear_interpolation_module.F90:256, :319-320
+    const int i = bracket(axis, sl.n, x);
+    c.ix[s * nz + j] = i;
+    c.q[s * nz + j] = (x - axis[i]) / (axis[i + 1] - axis[i]);  // linear_interpolation_module.F90:256, :319-320
   }
 }
 
-void launch_prep(const PrepParams &p, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, s, p); }
+void launch_prep(const PrepParams &p, hipStream_t s) {
+  hipLaunchKernelGGL(k_prep, dim3(1 + p.nslots), dim3(256), 0, s, p);
+}
 
 // ------------------------------------------------------------------------------------
 // k_opacity
@@ -111,21 +148,30 @@ __device__ __forceinline__ double lerp1(const double *f, int i, double q) {
 constexpr int OP_THREADS = 256;
 
 // Random-overlap resort + rebin for NG = 8 (k_rorr, types.f90:826-852), one lane per
-// (bin, layer).  X = current mixture tau_k(8), Y = new species' k*col (8), both in the
-// lane's private LDS slots sm[slot][tid].  The 64 sums X_i+Y_j are sorted by a Batcher
-// network held in registers; each key carries its pair index in the 6 low mantissa bits
-// (ordering ties exactly like a stable sort on (value,index) whenever the values differ
-// above 2^-46 relative), and the exact value is re-formed from X,Y when consumed.  The
-// sorted stream is deposited straight into the ng output bins (weights_to_bins + futils
-// rebin, types.f90:846-847) and written to sm[out+k][tid].
+// (bin, layer).  X = current mixture tau_k(8) and Y = new species' k*col (8) live in the
+// lane's private LDS slots sm[slot][tid] (slot-major: conflict-free for any per-lane
+// slot).  The 64 sums X_i+Y_j are sorted by a Batcher odd-even merge network held in
+// registers (one v_min_f64 + one v_max_f64 per compare-exchange).  Each key carries its
+// pair index in the 6 low mantissa bits -- that orders ties exactly like the stable rank
+// on (value,index) whenever two values differ above 2^-46 relative -- and the exact value
+// is re-formed from X,Y when the key is consumed.  When Y is already ascending (the normal
+// case for k-distributions) the 8 runs of 8 keys are pre-sorted and only the merge tail of
+// the network runs.
+// Rebin (weights_to_bins + futils rebin, types.f90:846-847): with c the running sum of
+// the sorted weights, the integral of the sorted step function up to each output edge
+// E_k is accumulated branch-free, I_k += v*(min(c1,E_k) - min(c0,E_k)); the new
+// coefficients are (I_k - I_{k-1}) / (E_k - E_{k-1}).
 __device__ __forceinline__ void rorr_mix8(double (*sm)[OP_THREADS], const int tid, const int xo,
-                                          const int yo, const int oo, const double *s_wxy,
-                                          const double *s_E) {
+                                          const int yo, const double *s_wxy, const double *E,
+                                          double *out) {
   double key[64];
+  bool ysorted = true;
   {
     double y[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) y[j] = sm[yo + j][tid];
+#pragma unroll
+    for (int j = 0; j < 7; j++) ysorted = ysorted && (y[j] <= y[j + 1]);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const double xi = sm[xo + i][tid];
@@ -138,56 +184,56 @@ __device__ __forceinline__ void rorr_mix8(double (*sm)[OP_THREADS], const int ti
       }
     }
   }
-#define CE(a, b)                                     \
-  {                                                  \
-    const double lo_ = __builtin_fmin(key[a], key[b]); \
-    const double hi_ = __builtin_fmax(key[a], key[b]); \
-    key[a] = lo_;                                    \
-    key[b] = hi_;                                    \
+#define CE(a, b)                              \
+  {                                           \
+    const double lo_ = dmin(key[a], key[b]);  \
+    const double hi_ = dmax(key[a], key[b]);  \
+    key[a] = lo_;                             \
+    key[b] = hi_;                             \
   }
+  if (!__all(ysorted)) {
 #define CE_FULL_HEAD
-#define CE_MERGE_TAIL
 #include "sort_network_64.inc"
 #undef CE_FULL_HEAD
+  }
+#define CE_MERGE_TAIL
+#include "sort_network_64.inc"
 #undef CE_MERGE_TAIL
 #undef CE
-  int k = 0;
-  double b0 = s_E[0], b1 = s_E[1];
-  double acc = 0.0, c0 = 0.0;
+  double I[8], m[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { I[k] = 0.0; m[k] = 0.0; }
+  double c0 = 0.0;
 #pragma unroll
   for (int p = 0; p < 64; p++) {
-    const int idx = (int)((unsigned long long)__double_as_longlong(key[p]) & 63ULL);
+    const unsigned lo32 = (unsigned)((unsigned long long)__double_as_longlong(key[p]) & 0xffffffffULL);
+    const int idx = (int)(lo32 & 63u);
     const double v = sm[xo + (idx >> 3)][tid] + sm[yo + (idx & 7)][tid];
     const double c1 = c0 + s_wxy[idx];  // weights_to_bins (clima_eqns.f90:43-54) on wxy(inds)
-    for (;;) {
-      const double lo = fmax(c0, b0), hi = fmin(c1, b1);
-      if (hi > lo) acc = acc + (hi - lo) * v;
-      if (c1 > b1 && k < 7) {
-        sm[oo + k][tid] = acc / (b1 - b0);
-        k++;
-        b0 = b1;
-        b1 = s_E[k + 1];
-        acc = 0.0;
-      } else {
-        break;
-      }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const double t = dmin(c1, E[k + 1]);
+      I[k] = __builtin_fma(v, t - m[k], I[k]);
+      m[k] = t;
     }
     c0 = c1;
   }
-  sm[oo + k][tid] = acc / (b1 - b0);
-  for (k = k + 1; k < 8; k++) sm[oo + k][tid] = 0.0;
+  out[0] = I[0] / (E[1] - E[0]);
+#pragma unroll
+  for (int k = 1; k < 8; k++) out[k] = (I[k] - I[k - 1]) / (E[k + 1] - E[k]);
 }
 
 __global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
   constexpr int NG = 8;
-  __shared__ double sm[3 * NG][OP_THREADS];  // per-lane private slots: X, Y, out
+  __shared__ double sm[2 * NG][OP_THREADS];  // per-lane private slots: X (0..7), Y (8..15)
   __shared__ double s_wxy[NG * NG];
-  __shared__ double s_E[NG + 1];
-  __shared__ double s_wbin[NG];
   const int tid = threadIdx.x;
   if (tid < NG * NG) s_wxy[tid] = p.wxy[tid];
-  if (tid < NG + 1) s_E[tid] = p.wbin_e[tid];
-  if (tid < NG) s_wbin[tid] = p.wbin[tid];
+  double E[NG + 1], wbin[NG];  // wave-uniform: scalar loads
+#pragma unroll
+  for (int k = 0; k < NG + 1; k++) E[k] = p.wbin_e[k];
+#pragma unroll
+  for (int k = 0; k < NG; k++) wbin[k] = p.wbin[k];
   __syncthreads();
 
   const int nz = p.nz;
@@ -255,7 +301,6 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
   gt = fmin(gt, MAX_GT);
 
   // ---- k-distributions (:649-662) and random-overlap mixing (k_rorr :816-854)
-  int xo = 0, oo = 2 * NG;
   for (int s = 0; s < p.nk; s++) {
     const KDev &kd = p.k[s];
     const int iP = c.ix[kd.slotP * nz + j], iT = c.ix[kd.slotT * nz + j];
@@ -267,7 +312,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
     const double *f12 = f11 + (size_t)kd.nP * NG;    // iT+1
     const double *f22 = f12 + NG;
     const double col = c.cols[kd.sp * nz + j];
-    const int dst = (s == 0) ? xo : NG;
+    const int dst = (s == 0) ? 0 : NG;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       // linear_interp_2d%evaluate, linear_interpolation_module.F90:319-327
@@ -276,19 +321,16 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
       const double kk = ten2power(p2 * fx1 + q2 * fx2);
       sm[dst + g][tid] = kk * col;  // :818 / :828
     }
-    if (s > 0) {
-      rorr_mix8(sm, tid, xo, NG, oo, s_wxy, s_E);
+    if (s > 0 && !(p.debug_skip & 1)) {
+      double out[NG];
+      rorr_mix8(sm, tid, 0, NG, s_wxy, E, out);
       // pair_reuse: the second layer of a pair copies the first layer's rebinned
       // mixture (:833-834).  Layer j-1 of the same bin lives in lane-1 (nz even).
 #pragma unroll
       for (int g = 0; g < NG; g++) {
-        const double mine = sm[oo + g][tid];
-        const double prev = __shfl_up(mine, 1);
-        if (reuse) sm[oo + g][tid] = prev;
+        const double prev = __shfl_up(out[g], 1);
+        sm[g][tid] = reuse ? prev : out[g];
       }
-      const int tmp = xo;
-      xo = oo;
-      oo = tmp;
     }
   }
 
@@ -298,13 +340,13 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
     const size_t base = ((size_t)l * NG) * nz + n;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-      const double tau = tausg + taua + taup + sm[xo + g][tid] + tauc;
+      const double tau = tausg + taua + taup + sm[g][tid] + tauc;
       double w0;
       if (tau <= TAU_MIN) w0 = 0.0;
       else w0 = fmin(MAX_W0, (tausg + tausp + tausc) / tau);
       p.tau[base + (size_t)g * nz] = tau;
       p.w0[base + (size_t)g * nz] = w0;
-      tb = tb + tau * s_wbin[g];
+      tb = tb + tau * wbin[g];
     }
     p.tau_band[(size_t)l * nz + n] = tb;
     p.g[(size_t)l * nz + n] = gt;
@@ -324,16 +366,31 @@ bool launch_opacity(const OpacityParams &p, hipStream_t s) {
 // k_twostream
 // ------------------------------------------------------------------------------------
 //
-// LDS image per block (bin): 4 arrays [nz][ng] f64 (pair index p = i*ng + c, layer i
-// TOA-first, g-point column c) that are recycled through the phases:
-//   G : cap_gamma      -> c' of row 2i+1      -> sum-over-g staging (fup)
-//   X : exp(-lambda t) -> c' of row 2i+2      -> staging (fdn)
-//   A : tau'/tauc, cp0 -> E of row 2i+1 -> d' -> Y(2i+1)=y2_i -> staging (amean)
-//   B : cm0            -> E of row 2i+2 -> d' -> Y(2i+2)=y1_{i+1}
-// Rows 0 and 2nz-1 live in layer nz-1's otherwise unused A/B slots.
-// Tridiagonal layout: SURVEY.md Appendix A / twostream.f90:91-117, :249-275.
+// One workgroup per (channel, bin[, g-point group]).  Work items are (layer i, column c)
+// pairs, p = i*nc + c (layer TOA-first, nc g-point columns in this block).  Unknown
+// ordering of the 2nz-row tridiagonal system follows the reference (SURVEY.md Appendix A,
+// twostream.f90:91-117, :249-275): rows 2i and 2i+1 (0-based) are y1_i and y2_i, so layer
+// i "owns" rows 2i, 2i+1:
+//     row 2i   (i>=1): couples layers i-1,i   (Fortran odd rows  l=2(i-1)+1, :97-103)
+//     row 2i+1 (i<nz-1): couples layers i,i+1 (Fortran even rows l=2i,       :106-112)
+//     row 0: top boundary (:93-96);  row 2nz-1: surface boundary (:113-117)
+//
+// LDS image: 6 arrays [nz][nc] f64, recycled through the phases
+//     G  : cap_gamma          -> c' row 2i    -> beta  row 2i    -> staging fup
+//     X  : exp(-lambda tau)   -> c' row 2i+1  -> beta  row 2i+1  -> staging fdn
+//     E0 : tau'/tauc, cp0     -> E  row 2i    -> d' -> alpha row 2i -> staging amean
+//     E1 : cm0                -> E  row 2i+1  -> d' -> alpha row 2i+1
+//     U  :                       l  row 2i    -> gamma row 2i
+//     V  :                       l  row 2i+1  -> gamma row 2i+1
+//
+// The solve is a domain-decomposed Thomas factorisation executed by ONE wave: every
+// column is cut into S chunks of consecutive layers, lane (chunk j, column c) solves
+// its chunk as a two-stream problem of its own (see dd_solve), the chunks are joined with
+// wave shuffles, and all threads finish their own rows in parallel.  Same elimination
+// arithmetic as tridiag (twostream.f90:297-316) inside a chunk; the dependent chain is S
+// times shorter.
 
-constexpr int TS_MAXP = 4;  // (layer, g) pairs per thread
+constexpr int TS_MAXP = 4;  // (layer, column) pairs per thread
 
 struct E4 {
   double e1, e2, e3, e4;
@@ -348,104 +405,168 @@ __device__ __forceinline__ E4 make_e(double G, double x) {
   return e;
 }
 
-// Thomas algorithm (tridiag, twostream.f90:297-316) for one column; rows are formed on
-// the fly from (G,X) of adjacent layers, inputs/outputs through the LDS image.
-__device__ void thomas_column(double *sG, double *sX, double *sA, double *sB, const int nz,
-                              const int ng, const int c, const double Rsfc) {
-  E4 e = make_e(sG[c], sX[c]);
-  // row 0 (:93-96): B=e1, D=-e2, E=-cm0(1) (staged in B[nz-1])
-  double cp = (-e.e2) / e.e1;
-  double dp = sB[(nz - 1) * ng + c] / e.e1;
-  const double c0p = cp, d0p = dp;
-  double Gn = 0.0, xn = 0.0, Ea = 0.0, Eb = 0.0;
-  if (nz > 1) {
-    Gn = sG[ng + c];
-    xn = sX[ng + c];
-    Ea = sA[c];
-    Eb = sB[c];
-  }
-  for (int i = 0; i < nz - 1; i++) {
-    const E4 f = make_e(Gn, xn);
-    const double Ea_i = Ea, Eb_i = Eb;
-    if (i + 1 < nz - 1) {  // prefetch next iteration's operands
-      Gn = sG[(i + 2) * ng + c];
-      xn = sX[(i + 2) * ng + c];
-      Ea = sA[(i + 1) * ng + c];
-      Eb = sB[(i + 1) * ng + c];
-    }
-    // row 2i+1 (Fortran even rows l=2i, :106-112)
-    double A = f.e2 * e.e1 - e.e3 * f.e4;
-    double B = e.e2 * f.e2 - e.e4 * f.e4;
-    double D = f.e1 * f.e4 - f.e2 * f.e3;
-    double den = B - A * cp;
-    double cn = D / den;
-    double dn = (Ea_i - A * dp) / den;
-    sG[i * ng + c] = cn;
-    sA[i * ng + c] = dn;
-    cp = cn;
-    dp = dn;
-    // row 2i+2 (Fortran odd rows l=2i+1, :97-103)
-    A = e.e2 * e.e3 - e.e4 * e.e1;
-    B = e.e1 * f.e1 - e.e3 * f.e3;
-    D = e.e3 * f.e4 - e.e1 * f.e2;
-    den = B - A * cp;
-    cn = D / den;
-    dn = (Eb_i - A * dp) / den;
-    sX[i * ng + c] = cn;
-    sB[i * ng + c] = dn;
-    cp = cn;
-    dp = dn;
-    e = f;
-  }
-  // last row (:113-117), E staged in A[nz-1]
-  {
-    const double A = e.e1 - Rsfc * e.e3;
-    const double B = e.e2 - Rsfc * e.e4;
-    const double ylast = (sA[(nz - 1) * ng + c] - A * dp) / (B - A * cp);
-    sA[(nz - 1) * ng + c] = ylast;  // y2_{nz-1}
-    double ynext = ylast;
-    for (int i = nz - 2; i >= 0; i--) {  // back substitution (:313-315)
-      const double yb = sB[i * ng + c] - sX[i * ng + c] * ynext;
-      sB[i * ng + c] = yb;  // y1_{i+1}
-      const double ya = sA[i * ng + c] - sG[i * ng + c] * yb;
-      sA[i * ng + c] = ya;  // y2_i
-      ynext = ya;
-    }
-    sB[(nz - 1) * ng + c] = d0p - c0p * ynext;  // y1_0
-  }
+struct TsLds {
+  double *G, *X, *E0, *E1, *U, *V;
+  double *Bp;    // [nz+1] Planck
+  double *L0;    // [3][nc] level-0 values
+  double *Seg;   // [nseg][nc] scan segment totals
+  double *Bnd;   // [2][S][nc] chunk parameters: Uin_j (up-flux entering at the bottom), Din_j
+  double *Ch;    // [4][S][nc] chunk constants: cp0,cm0 of its first layer, cpb,cmb of its last
+  int *chunk;    // [nz] chunk index of each layer
+};
+
+// chunk of layer i when nz layers are cut into S chunks [a_j,b_j), a_j = j*nz/S
+__device__ __forceinline__ int chunk_of(int i, int nz, int S) {
+  int j = ((i + 1) * S - 1) / nz;
+  while ((j * nz) / S > i) j--;
+  while (((j + 1) * nz) / S <= i) j++;
+  return j;
+}
+// pair index -> (layer, column)
+__device__ __forceinline__ void pair_split(int pr, int nc, int sh, int &i, int &c) {
+  if (sh >= 0) { i = pr >> sh; c = pr & (nc - 1); }
+  else { i = pr / nc; c = pr - i * nc; }
 }
 
-template <int MAXT>
-__global__ __launch_bounds__(MAXT) void k_twostream(TwoStreamParams p) {
+// Domain-decomposed two-stream solve.  Chunk j (layers [a,b)) is solved as a two-stream
+// problem of its own with flux boundary conditions
+//     top:    downward diffuse flux entering layer a   = Din_j   (row 2a:   -Din + e1 y1 - e2 y2 = -cm0_a)
+//     bottom: upward flux entering layer b-1 from below = Uin_j  (row 2b-1:  e1 y1 + e2 y2 - Uin = -cpb_{b-1})
+// (the first chunk keeps the reference's TOA row :93-96, the last its surface row :113-117),
+// i.e. the interface rows 2b-1, 2b of the global system are replaced by the two flux
+// conditions they encode.  Every chunk is a well-posed Toon system, so the Thomas sweeps
+// (tridiag, twostream.f90:297-316) keep their pivots; one downward sweep carries the
+// source column d' and the Din column l, the upward sweep yields for every row
+//     y_r = alpha_r + beta_r*Uin_j + gamma_r*Din_j.
+// Chunks are joined by flux continuity (adding method):
+//     Din_{j+1} = fdn at the bottom of chunk j = dS + dD*Din_j + dU*Uin_j
+//     Uin_j     = fup at the top of chunk j+1  = uS + uD*Din_{j+1} + uU*Uin_{j+1}
+// resolved per column with wave shuffles (one lane per chunk).
+__device__ void dd_solve(const TsLds &s, const int nz, const int nc, const int S,
+                         const int lane, const double Rsfc) {
+  const int j = lane / nc, c = lane - j * nc;
+  const int a = (j * nz) / S, b = ((j + 1) * nz) / S;  // layers [a,b)
+  const int len = b - a;
+  E4 u = make_e(0.0, 0.0);                               // layer i-1 (unused at i == a)
+  E4 v = make_e(s.G[a * nc + c], s.X[a * nc + c]);       // layer i
+  const E4 ea = v;
+  // ---- downward elimination: y_r + c' y_{r+1} + l*Din = d'
+  double cp = 0.0, dp = 0.0, lp = -1.0;
+  for (int t = 0; t < len; t++) {
+    const int i = a + t;
+    E4 w = v;  // layer i+1 (only needed inside the chunk)
+    if (i + 1 < b) w = make_e(s.G[(i + 1) * nc + c], s.X[(i + 1) * nc + c]);
+    const double Ea = s.E0[i * nc + c], Eb = s.E1[i * nc + c];
+    double A, B, D;
+    // row 2i
+    if (t == 0) { A = (a == 0) ? 0.0 : -1.0; B = v.e1; D = -v.e2; }
+    else { A = u.e2 * u.e3 - u.e4 * u.e1; B = u.e1 * v.e1 - u.e3 * v.e3; D = u.e3 * v.e4 - u.e1 * v.e2; }
+    double r = rcp_nr(B - A * cp);
+    double cn = D * r, dn = (Ea - A * dp) * r, ln = (-A * lp) * r;
+    s.G[i * nc + c] = cn; s.E0[i * nc + c] = dn; s.U[i * nc + c] = ln;
+    // row 2i+1
+    if (t == len - 1) {
+      if (b == nz) { A = v.e1 - Rsfc * v.e3; B = v.e2 - Rsfc * v.e4; D = 0.0; }
+      else { A = v.e1; B = v.e2; D = -1.0; }
+    } else {
+      A = w.e2 * v.e1 - v.e3 * w.e4; B = v.e2 * w.e2 - v.e4 * w.e4; D = w.e1 * w.e4 - w.e2 * w.e3;
+    }
+    r = rcp_nr(B - A * cn);
+    cp = D * r; dp = (Eb - A * dn) * r; lp = (-A * ln) * r;
+    s.X[i * nc + c] = cp; s.E1[i * nc + c] = dp; s.V[i * nc + c] = lp;
+    u = v; v = w;
+  }
+  const E4 eb = u;  // layer b-1
+  // ---- upward: y_r = alpha_r + beta_r*Uin + gamma_r*Din
+  double al = 0.0, be = 1.0, ga = 0.0;
+  double aB0 = 0, bB0 = 0, gB0 = 0, aB1 = 0, bB1 = 0, gB1 = 0;  // rows 2b-2, 2b-1
+  double aA1 = 0, bA1 = 0, gA1 = 0;                              // row 2a+1
+  for (int t = len - 1; t >= 0; t--) {
+    const int i = a + t;
+    double cc = s.X[i * nc + c], dd = s.E1[i * nc + c], ll = s.V[i * nc + c];
+    al = dd - cc * al; be = -cc * be; ga = -ll - cc * ga;
+    s.E1[i * nc + c] = al; s.X[i * nc + c] = be; s.V[i * nc + c] = ga;
+    if (t == len - 1) { aB1 = al; bB1 = be; gB1 = ga; }
+    if (t == 0) { aA1 = al; bA1 = be; gA1 = ga; }
+    cc = s.G[i * nc + c]; dd = s.E0[i * nc + c]; ll = s.U[i * nc + c];
+    al = dd - cc * al; be = -cc * be; ga = -ll - cc * ga;
+    s.E0[i * nc + c] = al; s.G[i * nc + c] = be; s.U[i * nc + c] = ga;
+    if (t == len - 1) { aB0 = al; bB0 = be; gB0 = ga; }
+  }
+  // outgoing fluxes of the chunk as affine functions of (Din, Uin):
+  //   up at its top    (fup(1)-form, :143):  y1 e3 - y2 e4 + cp0   (first layer)
+  //   down at its bottom (fdn(i+1), :147):   y1 e3 + y2 e4 + cmb   (last layer)
+  const double cp0a = s.Ch[(0 * S + j) * nc + c], cmbb = s.Ch[(3 * S + j) * nc + c];
+  const double uS = al * ea.e3 - aA1 * ea.e4 + cp0a, uD = ga * ea.e3 - gA1 * ea.e4, uU = be * ea.e3 - bA1 * ea.e4;
+  const double dS = aB0 * eb.e3 + aB1 * eb.e4 + cmbb, dD = gB0 * eb.e3 + gB1 * eb.e4, dU = bB0 * eb.e3 + bB1 * eb.e4;
+  // ---- adding recursion, identical in every lane of a column.
+  // bottom-up: Uin_{k-1} = rho_{k-1}*Din_k + sig_{k-1}
+  double rho = 0.0, sig = 0.0;            // for interface below chunk k (none below the last chunk)
+  double my_rho = 0.0, my_sig = 0.0;      // relation Uin_j = my_rho*Din_{j+1} + my_sig
+  for (int k = S - 1; k >= 1; k--) {
+    const int src = k * nc + c;
+    const double kuS = __shfl(uS, src), kuD = __shfl(uD, src), kuU = __shfl(uU, src);
+    const double kdS = __shfl(dS, src), kdD = __shfl(dD, src), kdU = __shfl(dU, src);
+    if (k == j) { my_rho = rho; my_sig = sig; }
+    // Uin_k = m*(rho*dS + sig + rho*dD*Din_k),  m = 1/(1 - rho*dU)
+    const double m = rcp_nr(1.0 - rho * kdU);
+    const double n_sig = kuS + kuU * m * (rho * kdS + sig);
+    const double n_rho = kuD + kuU * m * rho * kdD;
+    rho = n_rho; sig = n_sig;
+  }
+  if (j == 0) { my_rho = rho; my_sig = sig; }
+  // top-down: Din_0 = 0
+  double Din = 0.0, myDin = 0.0, myUin = 0.0;
+  for (int k = 0; k < S; k++) {
+    const int src = k * nc + c;
+    const double krho = __shfl(my_rho, src), ksig = __shfl(my_sig, src);
+    const double kdS = __shfl(dS, src), kdD = __shfl(dD, src), kdU = __shfl(dU, src);
+    const double m = rcp_nr(1.0 - krho * kdU);
+    const double Uin = (k == S - 1) ? 0.0 : m * (krho * kdS + ksig + krho * kdD * Din);
+    if (k == j) { myDin = Din; myUin = Uin; }
+    Din = kdS + kdD * Din + kdU * Uin;
+  }
+  s.Bnd[(0 * S + j) * nc + c] = myUin;
+  s.Bnd[(1 * S + j) * nc + c] = myDin;
+}
+
+template <int MAXT, int MINW>
+__global__ __launch_bounds__(MAXT, MINW) void k_twostream(TwoStreamParams p) {
   extern __shared__ __align__(16) double lds[];
-  const int nz = p.nz, ng = p.ng;
-  const int npairs = nz * ng;
-  double *sG = lds, *sX = lds + npairs, *sA = lds + 2 * npairs, *sB = lds + 3 * npairs;
-  double *sBp = lds + 4 * npairs;       // [nz+1] Planck (IR) / scratch
-  double *sL0 = sBp + (nz + 1);         // [3][ng] level-0 values per column
+  const int nz = p.nz, ng = p.ng, nc = p.ncols, S = p.nchunks;
+  const int cg0 = blockIdx.y * nc;  // first g-point column of this block
+  const int npairs = nz * nc;
+  TsLds s;
+  s.G = lds; s.X = s.G + npairs; s.E0 = s.X + npairs; s.E1 = s.E0 + npairs; s.U = s.E1 + npairs; s.V = s.U + npairs;
+  s.Bp = s.V + npairs; s.L0 = s.Bp + (nz + 1); s.Seg = s.L0 + 3 * nc; s.Bnd = s.Seg + ((nz + 7) / 8) * nc;
+  s.Ch = s.Bnd + 2 * S * nc;
+  s.chunk = (int *)(s.Ch + 4 * S * nc);
   const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < nz; i += nt) s.chunk[i] = chunk_of(i, nz, S);  // read after the next barrier
+  const int sh = p.nc_shift;  // log2(nc) when nc is a power of two, else -1
   const bool solar = (int)blockIdx.x < p.n_sol;
   const int ll = solar ? p.sol_lo + (int)blockIdx.x : p.ir_lo + ((int)blockIdx.x - p.n_sol);
   const int l = (solar ? p.sol_start : p.ir_start) + ll;  // opacity bin (radiate.f90:57)
-  const double *tauL = p.tau + (size_t)l * ng * nz;
-  const double *w0L = p.w0 + (size_t)l * ng * nz;
+  const double *tauL = p.tau + ((size_t)l * ng + cg0) * nz;
+  const double *w0L = p.w0 + ((size_t)l * ng + cg0) * nz;
   const double *gL = p.g + (size_t)l * nz;
 
   // values each thread keeps for its pairs across the solve
   double kG[TS_MAXP], kx[TS_MAXP], kcpb[TS_MAXP], kcmb[TS_MAXP], kdir[TS_MAXP], kdiru[TS_MAXP];
-  double cp0_first = 0.0;  // cp0 of layer 0 (pair k=0 of threads tid<ng)
+  double cp0_first = 0.0;  // cp0 of layer 0 (pair k=0 of threads tid<nc)
   double Rsfc;
 
   if (solar) {
     // =========================== solar (two_stream_solar, twostream.f90:10-154) ======
     Rsfc = p.albedo[ll];
-    double ktau[TS_MAXP], kw0[TS_MAXP], kgt[TS_MAXP], kg1[TS_MAXP], kg2[TS_MAXP], klam[TS_MAXP];
+    double ktau[TS_MAXP], kw0[TS_MAXP], kgt[TS_MAXP], klam[TS_MAXP];
     const double sqrt3 = 1.7320508075688772;  // sqrt(3.0_dp)
 #pragma unroll
     for (int k = 0; k < TS_MAXP; k++) {
       const int pr = tid + k * nt;
       if (pr < npairs) {
-        const int i = pr / ng, c = pr - i * ng;
+        int i, c;
+        pair_split(pr, nc, sh, i, c);
         const double tau_in = tauL[c * nz + i], w0_in = w0L[c * nz + i], gt_in = gL[i];
         // delta-Eddington (:38-40)
         const double tau = tau_in * (1.0 - w0_in * gt_in * gt_in);
@@ -455,21 +576,34 @@ __global__ __launch_bounds__(MAXT) void k_twostream(TwoStreamParams p) {
         const double gam1 = sqrt3 * (2.0 - w0 * (1 + gt)) / 2.0;
         const double gam2 = sqrt3 * w0 * (1.0 - gt) / 2.0;
         const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
-        const double G = gam2 / (gam1 + lam);
-        const double x = exp(-lam * tau);
-        ktau[k] = tau; kw0[k] = w0; kgt[k] = gt; kg1[k] = gam1; kg2[k] = gam2; klam[k] = lam;
-        kG[k] = G; kx[k] = x;
-        sA[pr] = tau;
+        ktau[k] = tau; kw0[k] = w0; kgt[k] = gt; klam[k] = lam;
+        kG[k] = gam2 / (gam1 + lam);
+        kx[k] = exp(-lam * tau);
+        s.E0[pr] = tau;
       }
     }
     __syncthreads();
-    // tauc (:64-67): cumulative optical depth at the top of each layer, sequential order
-    if (tid < ng) {
-      double cum = 0.0;
-      for (int i = 0; i < nz; i++) {
-        const double t = sA[i * ng + tid];
-        sA[i * ng + tid] = cum;
-        cum = cum + t;
+    // tauc (:64-67): optical depth above each layer.  Segmented scan: 8-layer segments
+    // summed in order, segment offsets summed in order.
+    {
+      const int nseg = (nz + 7) / 8;
+      int sg, c;
+      pair_split(tid, nc, sh, sg, c);
+      const int i0 = sg * 8, i1 = min(nz, i0 + 8);
+      if (sg < nseg) {
+        double ssum = 0.0;
+        for (int i = i0; i < i1; i++) ssum = ssum + s.E0[i * nc + c];
+        s.Seg[sg * nc + c] = ssum;
+      }
+      __syncthreads();
+      if (sg < nseg) {
+        double run = 0.0;
+        for (int s2 = 0; s2 < sg; s2++) run = run + s.Seg[s2 * nc + c];
+        for (int i = i0; i < i1; i++) {
+          const double t = s.E0[i * nc + c];
+          s.E0[i * nc + c] = run;
+          run = run + t;
+        }
       }
     }
     __syncthreads();
@@ -482,36 +616,39 @@ __global__ __launch_bounds__(MAXT) void k_twostream(TwoStreamParams p) {
     for (int k = 0; k < TS_MAXP; k++) {
       const int pr = tid + k * nt;
       if (pr < npairs) {
-        const double tauc = sA[pr];
+        const double tauc = s.E0[pr];
+        const double gam1 = sqrt3 * (2.0 - kw0[k] * (1 + kgt[k])) / 2.0;
+        const double gam2 = sqrt3 * kw0[k] * (1.0 - kgt[k]) / 2.0;
+        const double lam2 = klam[k] * klam[k];
         double CP0 = 0.0, CPB = 0.0, CM0 = 0.0, CMB = 0.0, DIR = 0.0, DIRU = 0.0;
-        for (int z = 0; z < p.nzen; z++) {
-          const double u0 = p.zen_u[z], wz = p.zen_w[z];
+        for (int z = 0; z < ((p.debug_skip & 2) ? 1 : p.nzen); z++) {
+          const double u0 = p.zen_u[z], wz = p.zen_w[z], iu = p.zen_iu[z];
           const double gam3 = (1.0 - sqrt3 * kgt[k] * u0) / 2.0;
           const double gam4 = 1.0 - gam3;
-          const double facp = kw0[k] * ((kg1[k] - 1.0 / u0) * gam3 + gam4 * kg2[k]);
-          const double facm = kw0[k] * ((kg1[k] + 1.0 / u0) * gam4 + kg2[k] * gam3);
-          const double et0 = exp(-tauc / u0);
-          const double etb = et0 * exp(-ktau[k] / u0);
-          const double denom = klam[k] * klam[k] - 1.0 / (u0 * u0);
-          const double direct = u0 * etb;
-          CP0 = CP0 + wz * (et0 * facp / denom);
-          CPB = CPB + wz * (etb * facp / denom);
-          CM0 = CM0 + wz * (et0 * facm / denom);
-          CMB = CMB + wz * (etb * facm / denom);
-          DIR = DIR + wz * direct;
-          DIRU = DIRU + wz * (direct / u0);
+          const double facp = kw0[k] * ((gam1 - iu) * gam3 + gam4 * gam2);
+          const double facm = kw0[k] * ((gam1 + iu) * gam4 + gam2 * gam3);
+          const double et0 = exp(-tauc * iu);
+          const double etb = et0 * exp(-ktau[k] * iu);
+          const double rden = wz * rcp_nr(lam2 - iu * iu);  // w_z / denom (:80)
+          const double fp = facp * rden, fm = facm * rden;
+          CP0 = __builtin_fma(et0, fp, CP0);
+          CPB = __builtin_fma(etb, fp, CPB);
+          CM0 = __builtin_fma(et0, fm, CM0);
+          CMB = __builtin_fma(etb, fm, CMB);
+          DIR = __builtin_fma(wz * u0, etb, DIR);   // direct(i+1) = u0*etb (:82)
+          DIRU = __builtin_fma(wz, etb, DIRU);      // direct(i+1)/u0
         }
         kcpb[k] = CPB; kcmb[k] = CMB; kdir[k] = DIR; kdiru[k] = DIRU;
-        sG[pr] = kG[k];
-        sX[pr] = kx[k];
-        sA[pr] = CP0;
-        sB[pr] = CM0;
-        if (pr < ng) cp0_first = CP0;
+        s.G[pr] = kG[k];
+        s.X[pr] = kx[k];
+        s.E0[pr] = CP0;
+        s.E1[pr] = CM0;
+        if (pr < nc) cp0_first = CP0;
       }
     }
-    if (tid < ng) {  // level-0 direct terms: direct(1)=u0 (:73), direct(1)/u0 = 1
-      sL0[1 * ng + tid] = dir0;
-      sL0[2 * ng + tid] = wsum;
+    if (tid < nc) {  // level-0 direct terms: direct(1)=u0 (:73), direct(1)/u0 = 1
+      s.L0[1 * nc + tid] = dir0;
+      s.L0[2 * nc + tid] = wsum;
     }
   } else {
     // =========================== IR (two_stream_ir, twostream.f90:156-295) ===========
@@ -519,14 +656,15 @@ __global__ __launch_bounds__(MAXT) void k_twostream(TwoStreamParams p) {
     Rsfc = p.has_hard_surface ? 1.0 - emis : 0.0;  // :186-190
     const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64
     for (int n = tid; n < nz + 1; n += nt)                        // radiate.f90:65-69
-      sBp[n] = planck_fcn(avg_freq, n == nz ? *p.T_surface : p.T[nz - 1 - n]);
+      s.Bp[n] = planck_fcn(avg_freq, n == nz ? *p.T_surface : p.T[nz - 1 - n]);
     __syncthreads();
     const double norm = 2.0 * PI * 0.5;
 #pragma unroll
     for (int k = 0; k < TS_MAXP; k++) {
       const int pr = tid + k * nt;
       if (pr < npairs) {
-        const int i = pr / ng, c = pr - i * ng;
+        int i, c;
+        pair_split(pr, nc, sh, i, c);
         const double tau = tauL[c * nz + i], w0 = w0L[c * nz + i], gt = gL[i];
         const double gam1 = 2.0 - w0 * (1.0 + gt);  // :195-201
         const double gam2 = w0 * (1.0 - gt);
@@ -535,11 +673,11 @@ __global__ __launch_bounds__(MAXT) void k_twostream(TwoStreamParams p) {
         const double x = exp(-lam * tau);
         double b0n, b1n;  // :216-227
         if (tau <= p.ir_tau_min) {
-          b0n = 0.5 * (sBp[i] + sBp[i + 1]);
+          b0n = 0.5 * (s.Bp[i] + s.Bp[i + 1]);
           b1n = 0.0;
         } else {
-          b0n = sBp[i];
-          b1n = (sBp[i + 1] - b0n) / tau;
+          b0n = s.Bp[i];
+          b1n = (s.Bp[i + 1] - b0n) / tau;
         }
         const double r = 1.0 / (gam1 + gam2);
         const double cp0 = norm * (b0n + b1n * (r));  // :229-232
@@ -547,47 +685,62 @@ __global__ __launch_bounds__(MAXT) void k_twostream(TwoStreamParams p) {
         const double cm0 = norm * (b0n + b1n * (-r));
         const double cmb = norm * (b0n + b1n * (tau - r));
         kG[k] = G; kx[k] = x; kcpb[k] = cpb; kcmb[k] = cmb; kdir[k] = 0.0; kdiru[k] = 0.0;
-        sG[pr] = G;
-        sX[pr] = x;
-        sA[pr] = cp0;
-        sB[pr] = cm0;
-        if (pr < ng) cp0_first = cp0;
+        s.G[pr] = G;
+        s.X[pr] = x;
+        s.E0[pr] = cp0;
+        s.E1[pr] = cm0;
+        if (pr < nc) cp0_first = cp0;
       }
     }
-    if (tid < ng) {
-      sL0[1 * ng + tid] = 0.0;  // fdn(1) = 0 (:289)
-      sL0[2 * ng + tid] = 0.0;
+    if (tid < nc) {
+      s.L0[1 * nc + tid] = 0.0;  // fdn(1) = 0 (:289)
+      s.L0[2 * nc + tid] = 0.0;
     }
   }
   __syncthreads();
 
-  // ---- right-hand sides (E of :102, :111, :96, :117) from neighbouring layers
-  double EA[TS_MAXP], EB[TS_MAXP];
+  // ---- right-hand sides from neighbouring layers: layer i's thread forms E(2i+1) (:111)
+  //      and E(2i+2) (:102); layer 0's also E(0) (:96); layer nz-1's E(2nz-1) (:117)
+  double R1[TS_MAXP], R2[TS_MAXP], R0 = 0.0;
 #pragma unroll
   for (int k = 0; k < TS_MAXP; k++) {
     const int pr = tid + k * nt;
-    EA[k] = 0.0; EB[k] = 0.0;
+    R1[k] = 0.0; R2[k] = 0.0;
     if (pr < npairs) {
-      const int i = pr / ng, c = pr - i * ng;
+      int i, c;
+      pair_split(pr, nc, sh, i, c);
       const E4 e = make_e(kG[k], kx[k]);
+      const int j = s.chunk[i];
+      if (i == 0) { R0 = 0.0 - s.E1[pr]; s.Ch[(0 * S + 0) * nc + c] = s.E0[pr]; }  // -cm0 of the top layer (:96)
       if (i < nz - 1) {
-        const E4 f = make_e(sG[pr + ng], sX[pr + ng]);
-        const double cp0n = sA[pr + ng], cm0n = sB[pr + ng];
-        EA[k] = f.e2 * (cp0n - kcpb[k]) - f.e4 * (cm0n - kcmb[k]);  // row 2i+1 (:111)
-        EB[k] = e.e3 * (cp0n - kcpb[k]) + e.e1 * (kcmb[k] - cm0n);  // row 2i+2 (:102)
+        const E4 f = make_e(s.G[pr + nc], s.X[pr + nc]);
+        const double cp0n = s.E0[pr + nc], cm0n = s.E1[pr + nc];
+        if (s.chunk[i + 1] != j) {
+          // chunk boundary below layer i: the two interface rows become flux conditions
+          R1[k] = 0.0 - kcpb[k];   // row 2i+1: fup entering layer i from below = Uin_j
+          R2[k] = 0.0 - cm0n;      // row 2i+2: fdn entering layer i+1 from above = Din_{j+1}
+          s.Ch[(2 * S + j) * nc + c] = kcpb[k];
+          s.Ch[(3 * S + j) * nc + c] = kcmb[k];
+          s.Ch[(0 * S + j + 1) * nc + c] = cp0n;
+          s.Ch[(1 * S + j + 1) * nc + c] = cm0n;
+        } else {
+          R1[k] = f.e2 * (cp0n - kcpb[k]) - f.e4 * (cm0n - kcmb[k]);  // row 2i+1 (:111)
+          R2[k] = e.e3 * (cp0n - kcpb[k]) + e.e1 * (kcmb[k] - cm0n);  // row 2i+2 (:102)
+        }
       } else {
         double Ssfc;
         if (solar) {
           Ssfc = Rsfc * kdir[k];  // :89 (zenith-weighted direct beam at the ground)
         } else if (p.has_hard_surface) {
-          Ssfc = p.emissivity[ll] * PI * sBp[nz];  // :237
+          Ssfc = p.emissivity[ll] * PI * s.Bp[nz];  // :237
         } else {  // :241-246
           const double tau = tauL[c * nz + i];
-          const double b1_bot = (tau <= p.ir_tau_min) ? 0.0 : (sBp[nz] - sBp[nz - 1]) / tau;
-          Ssfc = PI * (sBp[nz] + 0.5 * b1_bot);
+          const double b1_bot = (tau <= p.ir_tau_min) ? 0.0 : (s.Bp[nz] - s.Bp[nz - 1]) / tau;
+          Ssfc = PI * (s.Bp[nz] + 0.5 * b1_bot);
         }
-        EA[k] = Ssfc - kcpb[k] + Rsfc * kcmb[k];  // last row (:117)
-        EB[k] = 0.0 - sB[c];                      // row 0 (:96): -cm0 of the top layer
+        R1[k] = Ssfc - kcpb[k] + Rsfc * kcmb[k];  // row 2nz-1 (:117)
+        s.Ch[(2 * S + j) * nc + c] = kcpb[k];
+        s.Ch[(3 * S + j) * nc + c] = kcmb[k];
       }
     }
   }
@@ -595,12 +748,17 @@ __global__ __launch_bounds__(MAXT) void k_twostream(TwoStreamParams p) {
 #pragma unroll
   for (int k = 0; k < TS_MAXP; k++) {
     const int pr = tid + k * nt;
-    if (pr < npairs) { sA[pr] = EA[k]; sB[pr] = EB[k]; }
+    if (pr < npairs) {
+      const int i = (sh >= 0) ? (pr >> sh) : pr / nc;
+      s.E1[pr] = R1[k];
+      if (i < nz - 1) s.E0[pr + nc] = R2[k];
+      if (i == 0) s.E0[pr] = R0;
+    }
   }
   __syncthreads();
 
-  // ---- tridiagonal solve, one lane per g-point column
-  if (tid < ng) thomas_column(sG, sX, sA, sB, nz, ng, tid, Rsfc);
+  // ---- tridiagonal solve by one wave: S chunks x nc columns lanes
+  if (tid < S * nc && !(p.debug_skip & 1)) dd_solve(s, nz, nc, S, tid, Rsfc);
   __syncthreads();
 
   // ---- level fluxes (:143-148, :288-293) and mean intensity (:135-140)
@@ -611,17 +769,20 @@ __global__ __launch_bounds__(MAXT) void k_twostream(TwoStreamParams p) {
     const int pr = tid + k * nt;
     ofu[k] = ofd[k] = oam[k] = 0.0;
     if (pr < npairs) {
-      const int i = pr / ng, c = pr - i * ng;
+      int i, c;
+      pair_split(pr, nc, sh, i, c);
       const E4 e = make_e(kG[k], kx[k]);
-      const double y1 = (i == 0) ? sB[(nz - 1) * ng + c] : sB[pr - ng];
-      const double y2 = sA[pr];
+      const int j = s.chunk[i];
+      const double Uin = s.Bnd[(0 * S + j) * nc + c], Din = s.Bnd[(1 * S + j) * nc + c];
+      const double y1 = s.E0[pr] + s.G[pr] * Uin + s.U[pr] * Din;  // Y(2i)
+      const double y2 = s.E1[pr] + s.X[pr] * Uin + s.V[pr] * Din;  // Y(2i+1)
       ofu[k] = (y1 * e.e1 + y2 * e.e2 + kcpb[k]);
       ofd[k] = (y1 * e.e3 + y2 * e.e4 + kcmb[k]) + kdir[k];
       oam[k] = inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + kcpb[k] + kcmb[k]) + kdiru[k];
       if (i == 0) {
         const double top = (y1 * e.e3 - y2 * e.e4) + cp0_first;
-        sL0[c] = top;                                         // fup(1)
-        sL0[2 * ng + c] = inv_u1 * top + sL0[2 * ng + c];     // amean(1)
+        s.L0[c] = top;                                         // fup(1)
+        s.L0[2 * nc + c] = inv_u1 * top + s.L0[2 * nc + c];     // amean(1)
       }
     }
   }
@@ -629,89 +790,152 @@ __global__ __launch_bounds__(MAXT) void k_twostream(TwoStreamParams p) {
 #pragma unroll
   for (int k = 0; k < TS_MAXP; k++) {
     const int pr = tid + k * nt;
-    if (pr < npairs) { sG[pr] = ofu[k]; sX[pr] = ofd[k]; sA[pr] = oam[k]; }
+    if (pr < npairs) { s.G[pr] = ofu[k]; s.X[pr] = ofd[k]; s.E0[pr] = oam[k]; }
   }
   __syncthreads();
 
   // ---- g-point weights (radiate.f90:122-126), unit factors (:167-180), reversal to
-  //      ground-first (:140-154)
-  double scale = 1.0, am_scale = 0.0;
-  if (solar) {
-    scale = p.photons_sol[ll] * p.photon_scale_factor;  // clima_radtran.f90:302
-  }
+  //      ground-first (:140-154).  With several g-point groups per bin the groups add
+  //      their weighted partial sums into pre-zeroed outputs.
+  const bool split = gridDim.y > 1;
+  double scale = 1.0;
+  if (solar) scale = p.photons_sol[ll] * p.photon_scale_factor;  // clima_radtran.f90:302
   for (int n = tid; n < nz + 1; n += nt) {
     double fu = 0.0, fd = 0.0, am = 0.0;
-    for (int c = 0; c < ng; c++) {
-      const double w = p.wbin[c];
+    for (int c = 0; c < nc; c++) {
+      const double w = p.wbin[cg0 + c];
       if (n == 0) {
-        fu = fu + sL0[c] * w;
-        fd = fd + sL0[ng + c] * w;
-        am = am + sL0[2 * ng + c] * w;
+        fu = fu + s.L0[c] * w;
+        fd = fd + s.L0[nc + c] * w;
+        am = am + s.L0[2 * nc + c] * w;
       } else {
-        fu = fu + sG[(n - 1) * ng + c] * w;
-        fd = fd + sX[(n - 1) * ng + c] * w;
-        am = am + sA[(n - 1) * ng + c] * w;
+        fu = fu + s.G[(n - 1) * nc + c] * w;
+        fd = fd + s.X[(n - 1) * nc + c] * w;
+        am = am + s.E0[(n - 1) * nc + c] * w;
       }
     }
     const size_t o = (size_t)ll * (nz + 1) + (nz - n);
     if (solar) {
-      p.sol_fup_a[o] = fu * scale * p.diurnal_fac;
-      p.sol_fdn_a[o] = fd * scale * p.diurnal_fac;
+      fu = fu * scale * p.diurnal_fac;
+      fd = fd * scale * p.diurnal_fac;
       am = am * scale * p.diurnal_fac;
       am = am * p.am_f1[ll];
       am = am * p.am_f2[ll] * p.am_dw[ll];
-      p.sol_amean[o] = am;
+      if (split) { atomicAdd(&p.sol_fup_a[o], fu); atomicAdd(&p.sol_fdn_a[o], fd); atomicAdd(&p.sol_amean[o], am); }
+      else { p.sol_fup_a[o] = fu; p.sol_fdn_a[o] = fd; p.sol_amean[o] = am; }
     } else {
-      p.ir_fup_a[o] = fu;
-      p.ir_fdn_a[o] = fd;
+      if (split) { atomicAdd(&p.ir_fup_a[o], fu); atomicAdd(&p.ir_fdn_a[o], fd); }
+      else { p.ir_fup_a[o] = fu; p.ir_fdn_a[o] = fd; }
     }
   }
-  (void)am_scale;
-  double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
-  for (int i = tid; i < nz; i += nt) tb[(size_t)ll * nz + i] = p.tau_band[(size_t)l * nz + (nz - 1 - i)];
+  if (blockIdx.y == 0) {
+    double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
+    for (int i = tid; i < nz; i += nt) tb[(size_t)ll * nz + i] = p.tau_band[(size_t)l * nz + (nz - 1 - i)];
+  }
 }
 
-bool launch_twostream(const TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
-  const int npairs = p.nz * p.ng;
-  const size_t lds = sizeof(double) * ((size_t)4 * npairs + (p.nz + 1) + 3 * p.ng);
+// LDS bytes for nc columns per block
+static size_t ts_lds_bytes(int nz, int nc, int S) {
+  return sizeof(double) * ((size_t)6 * nz * nc + (nz + 1) + 3 * nc + (size_t)((nz + 7) / 8) * nc + (size_t)6 * S * nc + (size_t)(nz + 2) / 2 + 1);
+}
+
+bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
+  // columns per block: all g-points when the LDS image fits, else split the g-points over
+  // gridDim.y groups (outputs are then accumulated with atomics into zeroed arrays)
+  int nc = p.ncols;
+  if (nc <= 0) {
+    // prefer an LDS image small enough for 3 workgroups per CU (latency hiding), but never
+    // more than two g-point groups per bin: two partial sums added into a zeroed output
+    // are order-independent, so results stay bitwise reproducible
+    nc = p.ng;
+    if (ts_lds_bytes(p.nz, nc, 64 / nc) > 53 * 1024 && p.ng % 2 == 0) nc = p.ng / 2;
+  }
+  while (nc > 1 && (ts_lds_bytes(p.nz, nc, 64 / nc > 16 ? 16 : 64 / nc) > 150 * 1024 || p.ng % nc != 0 || nc > 64)) nc--;
+  if (p.ng % nc != 0) return false;
+  int S = 64 / nc;
+  if (S > 16) S = 16;
+  if (S > p.nz) S = p.nz;
+  if (S < 1) S = 1;
+  p.ncols = nc;
+  p.nchunks = S;
+  p.nc_shift = -1;
+  for (int b = 0; b < 7; b++) if ((1 << b) == nc) p.nc_shift = b;
+  const size_t lds = ts_lds_bytes(p.nz, nc, S);
   if (lds_bytes) *lds_bytes = lds;
   if (lds > 160 * 1024) return false;
+  const int npairs = p.nz * nc;
+  const int nseg = (p.nz + 7) / 8;
   int threads = (npairs + TS_MAXP - 1) / TS_MAXP;
   threads = ((threads + 63) / 64) * 64;
   if (threads < 64) threads = 64;
+  if (threads < nseg * nc) threads = ((nseg * nc + 63) / 64) * 64;
   if (threads > 1024) return false;
   const int grid = p.n_sol + p.n_ir;
   if (grid <= 0) return true;
+  const dim3 g(grid, p.ng / nc);
+  if (g.y > 1) {  // partial sums over g-point groups accumulate into zeroed outputs
+    const size_t nl = (size_t)p.nz + 1;
+    if (p.n_ir > 0) {
+      (void)hipMemsetAsync(p.ir_fup_a + (size_t)p.ir_lo * nl, 0, sizeof(double) * nl * p.n_ir, s);
+      (void)hipMemsetAsync(p.ir_fdn_a + (size_t)p.ir_lo * nl, 0, sizeof(double) * nl * p.n_ir, s);
+    }
+    if (p.n_sol > 0) {
+      (void)hipMemsetAsync(p.sol_fup_a + (size_t)p.sol_lo * nl, 0, sizeof(double) * nl * p.n_sol, s);
+      (void)hipMemsetAsync(p.sol_fdn_a + (size_t)p.sol_lo * nl, 0, sizeof(double) * nl * p.n_sol, s);
+      (void)hipMemsetAsync(p.sol_amean + (size_t)p.sol_lo * nl, 0, sizeof(double) * nl * p.n_sol, s);
+    }
+  }
   if (threads <= 512) {
     static bool attr512 = false;
-    if (!attr512) { (void)hipFuncSetAttribute((const void *)k_twostream<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr512 = true; }
-    hipLaunchKernelGGL(k_twostream<512>, dim3(grid), dim3(threads), lds, s, p);
+    if (!attr512) { (void)hipFuncSetAttribute((const void *)k_twostream<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr512 = true; }
+    hipLaunchKernelGGL((k_twostream<512, 4>), g, dim3(threads), lds, s, p);
   } else {
     static bool attr1024 = false;
-    if (!attr1024) { (void)hipFuncSetAttribute((const void *)k_twostream<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1024 = true; }
-    hipLaunchKernelGGL(k_twostream<1024>, dim3(grid), dim3(threads), lds, s, p);
+    if (!attr1024) { (void)hipFuncSetAttribute((const void *)k_twostream<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1024 = true; }
+    hipLaunchKernelGGL((k_twostream<1024, 4>), g, dim3(threads), lds, s, p);
   }
   return true;
 }
 
 // ------------------------------------------------------------------------------------
-// k_integrate: fup_n(i) = sum_l fup_a(i,l)*(freq(l)-freq(l+1)) in bin order
-// (radiate.f90:184-192); one thread per (array, level); then f_total (clima_radtran.f90:316)
+// spectral integration: fup_n(i) = sum_l fup_a(i,l)*(freq(l)-freq(l+1)) (radiate.f90:184-192)
+// in two deterministic stages (chunks of INT_CHUNK bins in bin order, then the chunk
+// sums in order), then f_total (clima_radtran.f90:316)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_integrate(IntegrateParams p) {
+constexpr int INT_CHUNK = 32;
+
+__global__ __launch_bounds__(256) void k_integrate_partial(IntegrateParams p) {
+  const int nl = p.nz + 1;
+  const int a = blockIdx.y;
+  const bool sol = a >= 2;
+  if (sol && !p.do_solar) return;
+  const double *src = a == 0 ? p.ir_fup_a : a == 1 ? p.ir_fdn_a : a == 2 ? p.sol_fup_a : p.sol_fdn_a;
+  const double *freq = sol ? p.sol_freq : p.ir_freq;
+  const int lo = sol ? p.sol_lo : p.ir_lo, cnt = sol ? p.sol_n : p.ir_n;
+  const int l0 = lo + blockIdx.x * INT_CHUNK;
+  const int l1 = min(lo + cnt, l0 + INT_CHUNK);
+  for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+    double acc = 0.0;
+    if (l0 < l1) {
+      double v[INT_CHUNK];
+#pragma unroll
+      for (int k = 0; k < INT_CHUNK; k++) v[k] = (l0 + k < l1) ? src[(size_t)(l0 + k) * nl + i] : 0.0;
+#pragma unroll
+      for (int k = 0; k < INT_CHUNK; k++)
+        if (l0 + k < l1) acc = acc + v[k] * (freq[l0 + k] - freq[l0 + k + 1]);
+    }
+    p.partial[((size_t)a * p.nchunk + blockIdx.x) * nl + i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_integrate_final(IntegrateParams p) {
   const int nl = p.nz + 1;
   for (int t = threadIdx.x; t < 4 * nl; t += blockDim.x) {
     const int a = t / nl, i = t - a * nl;
-    const bool sol = a >= 2;
-    if (sol && !p.do_solar) continue;
-    const double *src = a == 0 ? p.ir_fup_a : a == 1 ? p.ir_fdn_a : a == 2 ? p.sol_fup_a : p.sol_fdn_a;
-    const double *freq = sol ? p.sol_freq : p.ir_freq;
-    const int lo = sol ? p.sol_lo : p.ir_lo, cnt = sol ? p.sol_n : p.ir_n;
+    if (a >= 2 && !p.do_solar) continue;
     double acc = 0.0;
-    for (int l = lo; l < lo + cnt; l++) {
-      const double dfreq = freq[l] - freq[l + 1];
-      acc = acc + src[(size_t)l * nl + i] * dfreq;
-    }
+#pragma unroll 8
+    for (int k = 0; k < p.nchunk; k++) acc = acc + p.partial[((size_t)a * p.nchunk + k) * nl + i];
     p.flux_n[a * nl + i] = acc;
   }
   __syncthreads();
@@ -720,8 +944,11 @@ __global__ __launch_bounds__(1024) void k_integrate(IntegrateParams p) {
       p.f_total[i] = (p.flux_n[3 * nl + i] - p.flux_n[2 * nl + i]) + (p.flux_n[1 * nl + i] - p.flux_n[0 * nl + i]);
 }
 
+int integrate_chunks(int nbins) { return nbins <= 0 ? 1 : (nbins + INT_CHUNK - 1) / INT_CHUNK; }
+
 void launch_integrate(const IntegrateParams &p, hipStream_t s) {
-  hipLaunchKernelGGL(k_integrate, dim3(1), dim3(1024), 0, s, p);
+  hipLaunchKernelGGL(k_integrate_partial, dim3(p.nchunk, 4), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_integrate_final, dim3(1), dim3(1024), 0, s, p);
 }
 
 __global__ void k_f_total(int nl, const double *flux_n, double *f_total) {

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -118,7 +119,7 @@ struct Radtran {
   double ir_tau_min = 1.0e-6;
   double photon_scale_factor = 1.0;
   bool fields_dirty = true;
-  DevBuf<double> d_zen_u, d_zen_w, d_albedo, d_emis, d_photons, d_am_f1, d_am_f2, d_am_dw;
+  DevBuf<double> d_zen_u, d_zen_w, d_zen_iu, d_partial, d_albedo, d_emis, d_photons, d_am_f1, d_am_f2, d_am_dw;
   // column + prep
   int nslots = 0;
   std::vector<SlotDev> slots;
@@ -240,6 +241,11 @@ void upload_fields(Radtran *r) {
   if (!r->fields_dirty) return;
   r->d_zen_u.upload(r->zenith_u);
   r->d_zen_w.upload(r->zenith_w);
+  {
+    std::vector<double> iu(r->zenith_u.size());
+    for (size_t i = 0; i < iu.size(); i++) iu[i] = 1.0 / r->zenith_u[i];
+    r->d_zen_iu.upload(iu);
+  }
   r->d_albedo.upload(r->surface_albedo);
   r->d_emis.upload(r->surface_emissivity);
   r->d_photons.upload(r->photons_sol);
@@ -359,6 +365,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     std::memset(&op, 0, sizeof(op));
     op.nz = nz; op.nw = r->nw; op.ng = r->ng; op.nsp = r->nsp; op.np = r->np;
     op.bin_lo = r->op_lo; op.nbins = r->op_n;
+    if (const char *dbg = getenv("CLIMA_HIP_DEBUG_SKIP_OP")) op.debug_skip = atoi(dbg);
     op.nk = (int)r->k.size(); op.ncia = (int)r->cia.size(); op.nray = (int)r->ray.size();
     op.npxs = (int)r->pxs.size(); op.npart = (int)r->part.size();
     op.has_cont = r->has_cont; op.LH2O = r->LH2O; op.cont_nT = r->cont_nT;
@@ -394,6 +401,8 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   TwoStreamParams ts;
   std::memset(&ts, 0, sizeof(ts));
   ts.nz = nz; ts.ng = r->ng;
+  if (const char *dbg = getenv("CLIMA_HIP_DEBUG_SKIP_TS")) ts.debug_skip = atoi(dbg);
+  if (const char *nc = getenv("CLIMA_HIP_TS_NCOLS")) ts.ncols = atoi(nc);
   ts.n_sol = compute_solar ? r->sol_n : 0; ts.sol_lo = r->sol_lo;
   ts.n_ir = r->ir_n; ts.ir_lo = r->ir_lo;
   ts.sol_start = r->sol.ind_start; ts.ir_start = r->ir.ind_start;
@@ -401,7 +410,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   ts.wbin = r->d_wbin.p; ts.freq = r->d_freq.p;
   ts.T = col.T; ts.T_surface = col.T_surface;
   ts.emissivity = r->d_emis.p; ts.has_hard_surface = r->has_hard_surface ? 1 : 0; ts.ir_tau_min = r->ir_tau_min;
-  ts.nzen = (int)r->zenith_u.size(); ts.zen_u = r->d_zen_u.p; ts.zen_w = r->d_zen_w.p;
+  ts.nzen = (int)r->zenith_u.size(); ts.zen_u = r->d_zen_u.p; ts.zen_w = r->d_zen_w.p; ts.zen_iu = r->d_zen_iu.p;
   ts.albedo = r->d_albedo.p; ts.photons_sol = r->d_photons.p;
   ts.photon_scale_factor = r->photon_scale_factor; ts.diurnal_fac = r->diurnal_fac;
   ts.am_f1 = r->d_am_f1.p; ts.am_f2 = r->d_am_f2.p; ts.am_dw = r->d_am_dw.p;
@@ -425,6 +434,8 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   ip.ir_freq = r->ir.d_freq.p; ip.sol_freq = r->sol.d_freq.p;
   ip.flux_n = r->d_flux_n.p;
   ip.f_total = r->shard_world == 1 ? r->d_f_total.p : nullptr;
+  ip.nchunk = integrate_chunks(std::max(r->ir_n, r->sol_n));
+  ip.partial = r->d_partial.p;
   { KernelTimer t(r, 3); launch_integrate(ip, r->stream); t.stop(); }
   r->small_valid = false;
 }
@@ -718,6 +729,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   mk(r->wrk_ir, 0, r->ir.nw);
   mk(r->wrk_sol, 1, r->sol.nw);
   r->d_flux_n.alloc((size_t)4 * (nz + 1)); r->d_flux_n.zero();
+  r->d_partial.alloc((size_t)4 * integrate_chunks(std::max(r->ir.nw, r->sol.nw)) * (nz + 1)); r->d_partial.zero();
   r->d_f_total.alloc(nz + 1); r->d_f_total.zero();
   HIPCHK(hipHostMalloc((void **)&r->h_small, sizeof(double) * 5 * (nz + 1)));
   std::memset(r->h_small, 0, sizeof(double) * 5 * (nz + 1));
@@ -842,6 +854,12 @@ void radtran_set_bin_shard(void *ptr, const int *rank, const int *world, char *e
   r->d_flux_n.zero(r->stream);
   HIPCHK(hipStreamSynchronize(r->stream));
   CATCH(err)
+}
+
+void radtran_bin_shard_get(void *ptr, int *op_lo, int *op_n, int *ir_lo, int *ir_n, int *sol_lo, int *sol_n) {
+  Radtran *r = as_rad(ptr);
+  if (!r) return;
+  *op_lo = r->op_lo; *op_n = r->op_n; *ir_lo = r->ir_lo; *ir_n = r->ir_n; *sol_lo = r->sol_lo; *sol_n = r->sol_n;
 }
 
 void radtran_finish_reduced(void *ptr, char *err) {

@@ -78,6 +78,7 @@ struct ColumnDev {
 
 struct OpacityParams {
   int nz, nw, ng, nsp, np;
+  int debug_skip;  // developer ablation mask (0 in production)
   int bin_lo, nbins;  // opacity bins handled by this launch
   int nk, ncia, nray, npxs, npart, has_cont, LH2O, cont_slot, cont_nT;
   KDev k[MAX_K];
@@ -97,6 +98,8 @@ struct PrepParams {
 
 struct TwoStreamParams {
   int nz, ng;
+  int debug_skip;                          // developer ablation mask (0 in production)
+  int ncols, nchunks, nc_shift;            // g-point columns per block, chunks per column, log2(ncols) or -1 (launcher)
   // task list: blocks [0, n_sol) are solar bins sol_lo.., blocks [n_sol, n_sol+n_ir) IR bins
   int n_sol, sol_lo, n_ir, ir_lo;          // channel-local first bin of this launch
   int sol_start, ir_start;                 // channel -> opacity-bin offset (RTChannel%ind_start)
@@ -110,7 +113,7 @@ struct TwoStreamParams {
   double ir_tau_min;
   // solar
   int nzen;
-  const double *zen_u, *zen_w;
+  const double *zen_u, *zen_w, *zen_iu;    // cos(zenith), weights, 1/cos
   const double *albedo;                    // [nw_sol]
   const double *photons_sol;               // [nw_sol], unscaled
   double photon_scale_factor, diurnal_fac;
@@ -129,14 +132,17 @@ struct IntegrateParams {
   const double *ir_freq, *sol_freq;        // channel freq [nw_ch+1]
   double *flux_n;                          // [4][nz+1]
   double *f_total;
+  double *partial;                         // [4][nchunk][nz+1] chunk sums
+  int nchunk;
 };
 
 // launchers (kernels.hip)
 void launch_prep(const PrepParams &p, hipStream_t s);
 // returns false when ng is unsupported by the compiled kernels
 bool launch_opacity(const OpacityParams &p, hipStream_t s);
-bool launch_twostream(const TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
+bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
+int integrate_chunks(int nbins);
 void launch_f_total(int nz, const double *flux_n, double *f_total, hipStream_t s);
 void launch_scale(double *a, size_t n, double f, hipStream_t s);
 

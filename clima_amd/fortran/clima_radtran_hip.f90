@@ -1,0 +1,589 @@
+!> Fortran host side of the MI355X-native Radtran hot path.
+!>
+!> Drop-in shaped like the reference's `module clima_radtran` (src/radtran/clima_radtran.f90):
+!> `type(Radtran)` with the same public fields (:51-72), the same type-bound procedures
+!> `radiate` (:221-318), `TOA_fluxes` (:320-342), `apply_radiation_enhancement` (:402-411),
+!> `set_bolometric_flux` / `bolometric_flux` / `skin_temperature` /
+!> `equilibrium_temperature` (:345-382), and the result holders `wrk_ir`, `wrk_sol`
+!> (`type ClimaRadtranWrk`, :11-25), `ir`, `sol` (RTChannel), `f_total`.  Errors use the
+!> reference convention: `character(:), allocatable, intent(out) :: err`, allocated <=> failure.
+!>
+!> Everything numerical happens in hand-written HIP kernels behind the C ABI of
+!> include/clima_radtran_hip.h; this module only marshals arguments (ISO_C_BINDING).
+!> Construction takes the loaded tables instead of file names because the HDF5/YAML loaders
+!> (clima_radtran_types_create.f90) stay on the host side of the boundary:
+!>     call rad%begin(nz, species_count, particle_count, wavl, err)
+!>     call rad%add_ktable(...) ; call rad%add_xsection(...) ; ...
+!>     call rad%finish(num_zenith_angles, surface_albedo, err)
+module clima_radtran_hip
+  use iso_c_binding
+  implicit none
+  private
+
+  public :: Radtran, ClimaRadtranWrk, RTChannel, dp
+  public :: CIAXsection, RayleighXsection, AbsorptionXsection, PhotolysisXsection
+
+  integer, parameter :: dp = c_double
+  integer, parameter :: err_len = 1024
+  ! enum of src/radtran/clima_radtran_types.f90:40-42
+  integer, parameter :: CIAXsection = 0, RayleighXsection = 1, AbsorptionXsection = 2, PhotolysisXsection = 3
+
+  type :: ClimaRadtranWrk
+    real(dp), allocatable :: fup_a(:,:), fdn_a(:,:) !! (nz+1,nw) mW/m2/Hz
+    real(dp), allocatable :: fup_n(:), fdn_n(:)     !! (nz+1) mW/m2
+    real(dp), allocatable :: amean(:,:)             !! (nz+1,nw) photons/cm^2/s (solar)
+    real(dp), allocatable :: tau_band(:,:)          !! (nz,nw)
+  end type
+
+  type :: RTChannel
+    integer :: nw = 0
+    real(dp), allocatable :: wavl(:), freq(:)
+  end type
+
+  type :: Radtran
+    integer :: ng = 0   !! number of gases
+    integer :: np = 0   !! number of particles
+    integer :: nz = 0
+    type(RTChannel) :: ir, sol
+    real(dp) :: diurnal_fac = 0.5_dp
+    real(dp), allocatable :: zenith_u(:), zenith_weights(:)
+    real(dp), allocatable :: surface_albedo(:), surface_emissivity(:)
+    logical :: has_hard_surface = .true.
+    real(dp) :: ir_tau_min = 1.0e-6_dp
+    real(dp), allocatable :: photons_sol(:)
+    real(dp) :: photon_scale_factor = 1.0_dp
+    type(ClimaRadtranWrk) :: wrk_ir, wrk_sol
+    real(dp), allocatable :: f_total(:)
+    !> copy the per-bin spectra (fup_a, fdn_a, amean, tau_band) back after every radiate;
+    !> set to .false. when only the level fluxes are needed (saves ~7 MB of PCIe per call)
+    logical :: sync_spectra = .true.
+    type(c_ptr) :: handle = c_null_ptr
+  contains
+    procedure :: begin => Radtran_begin
+    procedure :: add_ktable => Radtran_add_ktable
+    procedure :: add_xsection => Radtran_add_xsection
+    procedure :: set_water_continuum => Radtran_set_water_continuum
+    procedure :: add_particle => Radtran_add_particle
+    procedure :: set_channels => Radtran_set_channels
+    procedure :: set_photons_sol => Radtran_set_photons_sol
+    procedure :: finish => Radtran_finish
+    procedure :: radiate => Radtran_radiate
+    procedure :: TOA_fluxes => Radtran_TOA_fluxes
+    procedure :: set_bolometric_flux => Radtran_set_bolometric_flux
+    procedure :: bolometric_flux => Radtran_bolometric_flux
+    procedure :: skin_temperature => Radtran_skin_temperature
+    procedure :: equilibrium_temperature => Radtran_equilibrium_temperature
+    procedure :: apply_radiation_enhancement => Radtran_apply_radiation_enhancement
+    procedure :: destroy => Radtran_destroy
+  end type
+
+  interface
+    subroutine c_allocate_radtran(ptr) bind(c, name="allocate_radtran")
+      import; type(c_ptr), intent(out) :: ptr
+    end subroutine
+    subroutine c_deallocate_radtran(ptr) bind(c, name="deallocate_radtran")
+      import; type(c_ptr), value :: ptr
+    end subroutine
+    subroutine c_radtran_create_begin(ptr, nz, nsp, np, nw, wavl, err) bind(c, name="radtran_create_begin")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: nz, nsp, np, nw
+      real(c_double), intent(in) :: wavl(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_add_ktable(ptr, sp_ind, ngauss, weights, npress, log10P, ntemp, temp, log10k, err) bind(c, name="radtran_add_ktable")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: sp_ind, ngauss, npress, ntemp
+      real(c_double), intent(in) :: weights(*), log10P(*), temp(*), log10k(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_add_xsection(ptr, xs_type, dim, sp_ind1, sp_ind2, ntemp, temp, data, err) bind(c, name="radtran_add_xsection")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: xs_type, dim, sp_ind1, sp_ind2, ntemp
+      real(c_double), intent(in) :: temp(*), data(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_set_water_continuum(ptr, LH2O, ntemp, temp, h2o, foreign, err) bind(c, name="radtran_set_water_continuum")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: LH2O, ntemp
+      real(c_double), intent(in) :: temp(*), h2o(*), foreign(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_add_particle(ptr, p_ind, nrad, radii, w0, qext, gt, err) bind(c, name="radtran_add_particle")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: p_ind, nrad
+      real(c_double), intent(in) :: radii(*), w0(*), qext(*), gt(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_set_channels(ptr, n_ir, ir_wavl, n_sol, sol_wavl, err) bind(c, name="radtran_set_channels")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: n_ir, n_sol
+      real(c_double), intent(in) :: ir_wavl(*), sol_wavl(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_set_photons_sol(ptr, n, photons_sol, err) bind(c, name="radtran_set_photons_sol")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: n
+      real(c_double), intent(in) :: photons_sol(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_create_end(ptr, nzen, albedo, err) bind(c, name="radtran_create_end")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: nzen
+      real(c_double), intent(in) :: albedo
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_radiate_wrapper(ptr, T_surface, dim_T, T, dim_P, P, dim1_d, dim2_d, densities, &
+                                       dim_dz, dz, has_particles, dim1_p, dim2_p, pdensities, radii, &
+                                       compute_solar, compute_opacity, err) bind(c, name="radtran_radiate_wrapper")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(in) :: T_surface
+      integer(c_int), intent(in) :: dim_T, dim_P, dim1_d, dim2_d, dim_dz, has_particles, dim1_p, dim2_p
+      real(c_double), intent(in) :: T(*), P(*), densities(*), dz(*), pdensities(*), radii(*)
+      integer(c_int), intent(in) :: compute_solar, compute_opacity
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_apply_radiation_enhancement(ptr, rad_enhancement) bind(c, name="radtran_apply_radiation_enhancement")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(in) :: rad_enhancement
+    end subroutine
+    subroutine c_radtran_set_bolometric_flux_wrapper(ptr, flux) bind(c, name="radtran_set_bolometric_flux_wrapper")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(in) :: flux
+    end subroutine
+    subroutine c_radtran_bolometric_flux_wrapper(ptr, flux) bind(c, name="radtran_bolometric_flux_wrapper")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(out) :: flux
+    end subroutine
+    subroutine c_radtran_skin_temperature_wrapper(ptr, bond_albedo, T_skin) bind(c, name="radtran_skin_temperature_wrapper")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(in) :: bond_albedo
+      real(c_double), intent(out) :: T_skin
+    end subroutine
+    subroutine c_radtran_equilibrium_temperature_wrapper(ptr, bond_albedo, T_eq) bind(c, name="radtran_equilibrium_temperature_wrapper")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(in) :: bond_albedo
+      real(c_double), intent(out) :: T_eq
+    end subroutine
+    subroutine c_radtran_zenith_u_get(ptr, dim1, arr) bind(c, name="radtran_zenith_u_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_radtran_zenith_u_set(ptr, dim1, arr) bind(c, name="radtran_zenith_u_set")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(in) :: arr(*)
+    end subroutine
+    subroutine c_radtran_zenith_weights_get(ptr, dim1, arr) bind(c, name="radtran_zenith_weights_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_radtran_zenith_weights_set(ptr, dim1, arr) bind(c, name="radtran_zenith_weights_set")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(in) :: arr(*)
+    end subroutine
+    subroutine c_radtran_surface_albedo_set(ptr, dim1, arr) bind(c, name="radtran_surface_albedo_set")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(in) :: arr(*)
+    end subroutine
+    subroutine c_radtran_surface_emissivity_set(ptr, dim1, arr) bind(c, name="radtran_surface_emissivity_set")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(in) :: arr(*)
+    end subroutine
+    subroutine c_radtran_has_hard_surface_set(ptr, val) bind(c, name="radtran_has_hard_surface_set")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: val
+    end subroutine
+    subroutine c_radtran_photon_scale_factor_set(ptr, val) bind(c, name="radtran_photon_scale_factor_set")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(in) :: val
+    end subroutine
+    subroutine c_radtran_photon_scale_factor_get(ptr, val) bind(c, name="radtran_photon_scale_factor_get")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(out) :: val
+    end subroutine
+    subroutine c_radtran_ir_tau_min_set(ptr, val) bind(c, name="radtran_ir_tau_min_set")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(in) :: val
+    end subroutine
+    subroutine c_radtran_diurnal_fac_set(ptr, val) bind(c, name="radtran_diurnal_fac_set")
+      import; type(c_ptr), value :: ptr
+      real(c_double), intent(in) :: val
+    end subroutine
+    subroutine c_radtran_ir_get(ptr, ptr1) bind(c, name="radtran_ir_get")
+      import; type(c_ptr), value :: ptr
+      type(c_ptr), intent(out) :: ptr1
+    end subroutine
+    subroutine c_radtran_sol_get(ptr, ptr1) bind(c, name="radtran_sol_get")
+      import; type(c_ptr), value :: ptr
+      type(c_ptr), intent(out) :: ptr1
+    end subroutine
+    subroutine c_radtran_wrk_ir_get(ptr, ptr1) bind(c, name="radtran_wrk_ir_get")
+      import; type(c_ptr), value :: ptr
+      type(c_ptr), intent(out) :: ptr1
+    end subroutine
+    subroutine c_radtran_wrk_sol_get(ptr, ptr1) bind(c, name="radtran_wrk_sol_get")
+      import; type(c_ptr), value :: ptr
+      type(c_ptr), intent(out) :: ptr1
+    end subroutine
+    subroutine c_radtran_f_total_get(ptr, dim1, arr) bind(c, name="radtran_f_total_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_rtchannel_wavl_get_size(ptr, dim1) bind(c, name="rtchannel_wavl_get_size")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(out) :: dim1
+    end subroutine
+    subroutine c_rtchannel_wavl_get(ptr, dim1, arr) bind(c, name="rtchannel_wavl_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_rtchannel_freq_get(ptr, dim1, arr) bind(c, name="rtchannel_freq_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_climaradtranwrk_fup_a_get(ptr, dim1, dim2, arr) bind(c, name="climaradtranwrk_fup_a_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1, dim2
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_climaradtranwrk_fdn_a_get(ptr, dim1, dim2, arr) bind(c, name="climaradtranwrk_fdn_a_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1, dim2
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_climaradtranwrk_amean_get(ptr, dim1, dim2, arr) bind(c, name="climaradtranwrk_amean_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1, dim2
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_climaradtranwrk_tau_band_get(ptr, dim1, dim2, arr) bind(c, name="climaradtranwrk_tau_band_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1, dim2
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_climaradtranwrk_fup_n_get(ptr, dim1, arr) bind(c, name="climaradtranwrk_fup_n_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_climaradtranwrk_fdn_n_get(ptr, dim1, arr) bind(c, name="climaradtranwrk_fdn_n_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
+  end interface
+
+contains
+
+  !> reference convention: allocated err <=> failure (clima/fortran/AdiabatClimate.f90:185-188 reversed)
+  subroutine take_err(err_c, err)
+    character(c_char), intent(in) :: err_c(err_len+1)
+    character(:), allocatable, intent(out) :: err
+    integer :: i, n
+    n = 0
+    do i = 1, err_len
+      if (err_c(i) == c_null_char) exit
+      n = n + 1
+    enddo
+    if (n > 0) then
+      allocate(character(n) :: err)
+      do i = 1, n
+        err(i:i) = err_c(i)
+      enddo
+    endif
+  end subroutine
+
+  subroutine Radtran_begin(self, nz, nsp, np, wavl, err)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: nz, nsp, np
+    real(dp), intent(in) :: wavl(:) !! (nw+1) nm
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    if (c_associated(self%handle)) call c_deallocate_radtran(self%handle)
+    call c_allocate_radtran(self%handle)
+    self%nz = nz; self%ng = nsp; self%np = np
+    call c_radtran_create_begin(self%handle, nz, nsp, np, size(wavl)-1, wavl, err_c)
+    call take_err(err_c, err)
+  end subroutine
+
+  subroutine Radtran_add_ktable(self, sp_ind, weights, log10P, temp, log10k, err)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: sp_ind !! 1-based species index (Ktable%sp_ind)
+    real(dp), intent(in) :: weights(:), log10P(:), temp(:)
+    real(dp), intent(in) :: log10k(:,:,:,:) !! (ngauss,npress,ntemp,nwav), types_create.f90:1349-1358
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    call c_radtran_add_ktable(self%handle, sp_ind, size(weights), weights, size(log10P), log10P, &
+                            size(temp), temp, log10k, err_c)
+    call take_err(err_c, err)
+  end subroutine
+
+  subroutine Radtran_add_xsection(self, xs_type, sp_ind, xs_0d, temp, log10_xs_1d, err)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: xs_type
+    integer, intent(in) :: sp_ind(:) !! 1 or 2 species (Xsection%sp_ind)
+    real(dp), optional, intent(in) :: xs_0d(:)          !! (nw)
+    real(dp), optional, intent(in) :: temp(:)           !! (ntemp)
+    real(dp), optional, intent(in) :: log10_xs_1d(:,:)  !! (ntemp,nw)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    integer :: sp2
+    real(dp) :: dummy(1)
+    sp2 = 0
+    if (size(sp_ind) > 1) sp2 = sp_ind(2)
+    dummy = 0.0_dp
+    if (present(xs_0d)) then
+      call c_radtran_add_xsection(self%handle, xs_type, 0, sp_ind(1), sp2, 0, dummy, xs_0d, err_c)
+    elseif (present(temp) .and. present(log10_xs_1d)) then
+      call c_radtran_add_xsection(self%handle, xs_type, 1, sp_ind(1), sp2, size(temp), temp, log10_xs_1d, err_c)
+    else
+      err = 'add_xsection needs either xs_0d or temp and log10_xs_1d'
+      return
+    endif
+    call take_err(err_c, err)
+  end subroutine
+
+  subroutine Radtran_set_water_continuum(self, LH2O, temp, log10_xs_H2O, log10_xs_foreign, err)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: LH2O
+    real(dp), intent(in) :: temp(:), log10_xs_H2O(:,:), log10_xs_foreign(:,:) !! (ntemp,nw)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    call c_radtran_set_water_continuum(self%handle, LH2O, size(temp), temp, log10_xs_H2O, log10_xs_foreign, err_c)
+    call take_err(err_c, err)
+  end subroutine
+
+  subroutine Radtran_add_particle(self, p_ind, radii, w0, qext, gt, err)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: p_ind
+    real(dp), intent(in) :: radii(:), w0(:,:), qext(:,:), gt(:,:) !! (nrad,nw)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    call c_radtran_add_particle(self%handle, p_ind, size(radii), radii, w0, qext, gt, err_c)
+    call take_err(err_c, err)
+  end subroutine
+
+  subroutine Radtran_set_channels(self, ir_wavl, sol_wavl, err)
+    class(Radtran), intent(inout) :: self
+    real(dp), intent(in) :: ir_wavl(:), sol_wavl(:)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    call c_radtran_set_channels(self%handle, size(ir_wavl), ir_wavl, size(sol_wavl), sol_wavl, err_c)
+    call take_err(err_c, err)
+  end subroutine
+
+  subroutine Radtran_set_photons_sol(self, photons_sol, err)
+    class(Radtran), intent(inout) :: self
+    real(dp), intent(in) :: photons_sol(:)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    call c_radtran_set_photons_sol(self%handle, size(photons_sol), photons_sol, err_c)
+    call take_err(err_c, err)
+    if (.not. allocated(err)) self%photons_sol = photons_sol
+  end subroutine
+
+  !> rest of create_Radtran_2 (clima_radtran.f90:162-217)
+  subroutine Radtran_finish(self, num_zenith_angles, surface_albedo, err)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: num_zenith_angles
+    real(dp), intent(in) :: surface_albedo
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    type(c_ptr) :: p
+    integer(c_int) :: n
+    integer :: nz
+    call c_radtran_create_end(self%handle, num_zenith_angles, surface_albedo, err_c)
+    call take_err(err_c, err)
+    if (allocated(err)) return
+    nz = self%nz
+    allocate(self%zenith_u(num_zenith_angles), self%zenith_weights(num_zenith_angles))
+    call c_radtran_zenith_u_get(self%handle, num_zenith_angles, self%zenith_u)
+    call c_radtran_zenith_weights_get(self%handle, num_zenith_angles, self%zenith_weights)
+    call c_radtran_ir_get(self%handle, p)
+    call c_rtchannel_wavl_get_size(p, n)
+    self%ir%nw = n - 1
+    allocate(self%ir%wavl(n), self%ir%freq(n))
+    call c_rtchannel_wavl_get(p, n, self%ir%wavl)
+    call c_rtchannel_freq_get(p, n, self%ir%freq)
+    call c_radtran_sol_get(self%handle, p)
+    call c_rtchannel_wavl_get_size(p, n)
+    self%sol%nw = n - 1
+    allocate(self%sol%wavl(n), self%sol%freq(n))
+    call c_rtchannel_wavl_get(p, n, self%sol%wavl)
+    call c_rtchannel_freq_get(p, n, self%sol%freq)
+    allocate(self%surface_albedo(self%sol%nw)); self%surface_albedo = surface_albedo
+    allocate(self%surface_emissivity(self%ir%nw)); self%surface_emissivity = 1.0_dp
+    if (.not. allocated(self%photons_sol)) then
+      allocate(self%photons_sol(self%sol%nw)); self%photons_sol = 0.0_dp
+    endif
+    call alloc_wrk(self%wrk_ir, nz, self%ir%nw)
+    call alloc_wrk(self%wrk_sol, nz, self%sol%nw)
+    allocate(self%f_total(nz+1)); self%f_total = 0.0_dp
+  contains
+    subroutine alloc_wrk(w, nz, nw)
+      type(ClimaRadtranWrk), intent(inout) :: w
+      integer, intent(in) :: nz, nw
+      allocate(w%fup_a(nz+1,nw), w%fdn_a(nz+1,nw), w%amean(nz+1,nw), w%tau_band(nz,nw), w%fup_n(nz+1), w%fdn_n(nz+1))
+      w%fup_a = 0.0_dp; w%fdn_a = 0.0_dp; w%amean = 0.0_dp; w%tau_band = 0.0_dp; w%fup_n = 0.0_dp; w%fdn_n = 0.0_dp
+    end subroutine
+  end subroutine
+
+  !> the public fields are read on every radiate (clima_radtran.f90:262-313)
+  subroutine push_fields(self)
+    class(Radtran), intent(inout) :: self
+    integer(c_int) :: hs
+    call c_radtran_zenith_u_set(self%handle, size(self%zenith_u), self%zenith_u)
+    call c_radtran_zenith_weights_set(self%handle, size(self%zenith_weights), self%zenith_weights)
+    call c_radtran_surface_albedo_set(self%handle, size(self%surface_albedo), self%surface_albedo)
+    call c_radtran_surface_emissivity_set(self%handle, size(self%surface_emissivity), self%surface_emissivity)
+    hs = 0
+    if (self%has_hard_surface) hs = 1
+    call c_radtran_has_hard_surface_set(self%handle, hs)
+    call c_radtran_photon_scale_factor_set(self%handle, self%photon_scale_factor)
+    call c_radtran_ir_tau_min_set(self%handle, self%ir_tau_min)
+    call c_radtran_diurnal_fac_set(self%handle, self%diurnal_fac)
+  end subroutine
+
+  subroutine pull_results(self, do_solar)
+    class(Radtran), intent(inout) :: self
+    logical, intent(in) :: do_solar
+    type(c_ptr) :: p
+    integer :: nz
+    nz = self%nz
+    call c_radtran_wrk_ir_get(self%handle, p)
+    call c_climaradtranwrk_fup_n_get(p, nz+1, self%wrk_ir%fup_n)
+    call c_climaradtranwrk_fdn_n_get(p, nz+1, self%wrk_ir%fdn_n)
+    if (self%sync_spectra) then
+      call c_climaradtranwrk_fup_a_get(p, nz+1, self%ir%nw, self%wrk_ir%fup_a)
+      call c_climaradtranwrk_fdn_a_get(p, nz+1, self%ir%nw, self%wrk_ir%fdn_a)
+      call c_climaradtranwrk_tau_band_get(p, nz, self%ir%nw, self%wrk_ir%tau_band)
+    endif
+    if (do_solar) then
+      call c_radtran_wrk_sol_get(self%handle, p)
+      call c_climaradtranwrk_fup_n_get(p, nz+1, self%wrk_sol%fup_n)
+      call c_climaradtranwrk_fdn_n_get(p, nz+1, self%wrk_sol%fdn_n)
+      if (self%sync_spectra) then
+        call c_climaradtranwrk_fup_a_get(p, nz+1, self%sol%nw, self%wrk_sol%fup_a)
+        call c_climaradtranwrk_fdn_a_get(p, nz+1, self%sol%nw, self%wrk_sol%fdn_a)
+        call c_climaradtranwrk_amean_get(p, nz+1, self%sol%nw, self%wrk_sol%amean)
+        call c_climaradtranwrk_tau_band_get(p, nz, self%sol%nw, self%wrk_sol%tau_band)
+      endif
+    endif
+    call c_radtran_f_total_get(self%handle, nz+1, self%f_total)
+  end subroutine
+
+  !> Radtran%radiate (clima_radtran.f90:221-318), same argument list
+  subroutine Radtran_radiate(self, T_surface, T, P, densities, dz, pdensities, radii, compute_solar, compute_opacity, err)
+    class(Radtran), target, intent(inout) :: self
+    real(dp), intent(in) :: T_surface
+    real(dp), intent(in) :: T(:) !! (nz) K
+    real(dp), intent(in) :: P(:) !! (nz) bars
+    real(dp), intent(in) :: densities(:,:) !! (nz,ng) molecules/cm3
+    real(dp), intent(in) :: dz(:) !! (nz) cm
+    real(dp), optional, target, intent(in) :: pdensities(:,:), radii(:,:)
+    logical, optional, intent(in) :: compute_solar, compute_opacity
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    integer(c_int) :: cs, co, hp, p1, p2
+    real(dp) :: dummy(1)
+    logical :: do_solar
+
+    ! check_inputs, clima_radtran.f90:426-430 (presence is only visible on this side)
+    if ((present(pdensities) .and. .not. present(radii)) .or. (present(radii) .and. .not. present(pdensities))) then
+      err = 'Both pdensities and radii must be arguments.'
+      return
+    endif
+    cs = 1; co = 1
+    if (present(compute_solar)) cs = merge(1, 0, compute_solar)
+    if (present(compute_opacity)) co = merge(1, 0, compute_opacity)
+    do_solar = cs == 1
+    call push_fields(self)
+    dummy = 0.0_dp
+    if (present(radii)) then
+      hp = 1; p1 = size(pdensities,1); p2 = size(pdensities,2)
+      if (size(radii,1) /= p1 .or. size(radii,2) /= p2) then
+        err = '"radii" has the wrong input dimension.'
+        return
+      endif
+      call c_radtran_radiate_wrapper(self%handle, T_surface, size(T), T, size(P), P, size(densities,1), &
+                                   size(densities,2), densities, size(dz), dz, hp, p1, p2, pdensities, radii, &
+                                   cs, co, err_c)
+    else
+      hp = 0; p1 = 0; p2 = 0
+      call c_radtran_radiate_wrapper(self%handle, T_surface, size(T), T, size(P), P, size(densities,1), &
+                                   size(densities,2), densities, size(dz), dz, hp, p1, p2, dummy, dummy, &
+                                   cs, co, err_c)
+    endif
+    call take_err(err_c, err)
+    if (allocated(err)) return
+    call pull_results(self, do_solar)
+  end subroutine
+
+  !> Radtran%TOA_fluxes (clima_radtran.f90:320-342)
+  subroutine Radtran_TOA_fluxes(self, T_surface, T, P, densities, dz, pdensities, radii, &
+                                compute_solar, compute_opacity, ISR, OLR, err)
+    class(Radtran), target, intent(inout) :: self
+    real(dp), intent(in) :: T_surface
+    real(dp), intent(in) :: T(:), P(:), densities(:,:), dz(:)
+    real(dp), optional, target, intent(in) :: pdensities(:,:), radii(:,:)
+    logical, optional, intent(in) :: compute_solar, compute_opacity
+    real(dp), intent(out) :: ISR, OLR
+    character(:), allocatable, intent(out) :: err
+    call self%radiate(T_surface, T, P, densities, dz, pdensities, radii, compute_solar, compute_opacity, err)
+    if (allocated(err)) return
+    ISR = (self%wrk_sol%fdn_n(self%nz+1) - self%wrk_sol%fup_n(self%nz+1))
+    OLR = - (self%wrk_ir%fdn_n(self%nz+1) - self%wrk_ir%fup_n(self%nz+1))
+  end subroutine
+
+  subroutine Radtran_set_bolometric_flux(self, flux)
+    class(Radtran), target, intent(inout) :: self
+    real(dp), intent(in) :: flux !! W/m^2
+    call c_radtran_set_bolometric_flux_wrapper(self%handle, flux)
+    call c_radtran_photon_scale_factor_get(self%handle, self%photon_scale_factor)
+  end subroutine
+
+  function Radtran_bolometric_flux(self) result(flux)
+    class(Radtran), target, intent(inout) :: self
+    real(dp) :: flux
+    call c_radtran_photon_scale_factor_set(self%handle, self%photon_scale_factor)
+    call c_radtran_bolometric_flux_wrapper(self%handle, flux)
+  end function
+
+  function Radtran_skin_temperature(self, bond_albedo) result(T_skin)
+    class(Radtran), target, intent(inout) :: self
+    real(dp), intent(in) :: bond_albedo
+    real(dp) :: T_skin
+    call c_radtran_photon_scale_factor_set(self%handle, self%photon_scale_factor)
+    call c_radtran_skin_temperature_wrapper(self%handle, bond_albedo, T_skin)
+  end function
+
+  function Radtran_equilibrium_temperature(self, bond_albedo) result(T_eq)
+    class(Radtran), target, intent(inout) :: self
+    real(dp), intent(in) :: bond_albedo
+    real(dp) :: T_eq
+    call c_radtran_photon_scale_factor_set(self%handle, self%photon_scale_factor)
+    call c_radtran_equilibrium_temperature_wrapper(self%handle, bond_albedo, T_eq)
+  end function
+
+  subroutine Radtran_apply_radiation_enhancement(self, rad_enhancement)
+    class(Radtran), target, intent(inout) :: self
+    real(dp), intent(in) :: rad_enhancement
+    call c_radtran_apply_radiation_enhancement(self%handle, rad_enhancement)
+    call pull_results(self, .true.)
+  end subroutine
+
+  subroutine Radtran_destroy(self)
+    class(Radtran), intent(inout) :: self
+    if (c_associated(self%handle)) call c_deallocate_radtran(self%handle)
+    self%handle = c_null_ptr
+  end subroutine
+
+end module

@@ -1,0 +1,128 @@
+!> Fortran host program in the shape of the reference's tests/test_radtran.f90: build a
+!> `Radtran`, call `rad%radiate` once, print `rad%wrk_sol%fdn_n(nz+1)*1e-3`, dump results.
+!> The tables and the column come from a binary case file written by
+!> clima_amd/fortran_case.py (the reference reads YAML/HDF5/atmosphere.txt here; those
+!> loaders are outside the hot path).  Usage: radtran_driver case.bin result.txt
+program radtran_driver
+  use iso_fortran_env, only: int32, output_unit
+  use clima_radtran_hip, only: Radtran, dp
+  implicit none
+  type(Radtran) :: rad
+  character(:), allocatable :: err
+  character(1024) :: fin, fout
+  integer(int32) :: nz, nsp, np, nw, nzen, nk, nxs, has_cont, npart, n_ir, n_sol
+  integer(int32) :: sp_ind, ng, npr, nT, xs_type, xdim, sp1, sp2, LH2O, p_ind, nrad
+  real(dp) :: albedo, T_surface, ISR, OLR
+  real(dp), allocatable :: wavl(:), weights(:), log10P(:), temp(:), log10k(:,:,:,:), xs0(:), xs1(:,:)
+  real(dp), allocatable :: h2o(:,:), frn(:,:), radii_ax(:), w0(:,:), qext(:,:), gt(:,:)
+  real(dp), allocatable :: ir_wavl(:), sol_wavl(:), photons(:)
+  real(dp), allocatable :: T(:), P(:), densities(:,:), dz(:), pdensities(:,:), radii(:,:)
+  integer :: i, u
+
+  call get_command_argument(1, fin)
+  call get_command_argument(2, fout)
+  open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
+  read(u) nz, nsp, np, nw, nzen
+  read(u) albedo
+  allocate(wavl(nw+1)); read(u) wavl
+  call rad%begin(nz, nsp, np, wavl, err); call check()
+  read(u) nk
+  do i = 1, nk
+    read(u) sp_ind, ng, npr, nT
+    allocate(weights(ng), log10P(npr), temp(nT), log10k(ng,npr,nT,nw))
+    read(u) weights; read(u) log10P; read(u) temp; read(u) log10k
+    call rad%add_ktable(sp_ind, weights, log10P, temp, log10k, err); call check()
+    deallocate(weights, log10P, temp, log10k)
+  enddo
+  read(u) nxs
+  do i = 1, nxs
+    read(u) xs_type, xdim, sp1, sp2, nT
+    if (xdim == 0) then
+      allocate(xs0(nw)); read(u) xs0
+      call rad%add_xsection(xs_type, [sp1, sp2], xs_0d=xs0, err=err); call check()
+      deallocate(xs0)
+    else
+      allocate(temp(nT), xs1(nT,nw)); read(u) temp; read(u) xs1
+      call rad%add_xsection(xs_type, [sp1, sp2], temp=temp, log10_xs_1d=xs1, err=err); call check()
+      deallocate(temp, xs1)
+    endif
+  enddo
+  read(u) has_cont
+  if (has_cont == 1) then
+    read(u) LH2O, nT
+    allocate(temp(nT), h2o(nT,nw), frn(nT,nw)); read(u) temp; read(u) h2o; read(u) frn
+    call rad%set_water_continuum(LH2O, temp, h2o, frn, err); call check()
+    deallocate(temp, h2o, frn)
+  endif
+  read(u) npart
+  do i = 1, npart
+    read(u) p_ind, nrad
+    allocate(radii_ax(nrad), w0(nrad,nw), qext(nrad,nw), gt(nrad,nw))
+    read(u) radii_ax; read(u) w0; read(u) qext; read(u) gt
+    call rad%add_particle(p_ind, radii_ax, w0, qext, gt, err); call check()
+    deallocate(radii_ax, w0, qext, gt)
+  enddo
+  read(u) n_ir; allocate(ir_wavl(n_ir)); read(u) ir_wavl
+  read(u) n_sol; allocate(sol_wavl(n_sol)); read(u) sol_wavl
+  call rad%set_channels(ir_wavl, sol_wavl, err); call check()
+  allocate(photons(n_sol-1)); read(u) photons
+  call rad%set_photons_sol(photons, err); call check()
+  call rad%finish(nzen, albedo, err); call check()
+
+  allocate(T(nz), P(nz), densities(nz,nsp), dz(nz), pdensities(nz,np), radii(nz,np))
+  read(u) T_surface; read(u) T; read(u) P; read(u) densities; read(u) dz
+  if (np > 0) then
+    read(u) pdensities; read(u) radii
+  endif
+  close(u)
+
+  ! tests/test_radtran.f90:67
+  if (np > 0) then
+    call rad%radiate(T_surface, T, P, densities, dz, pdensities, radii, err=err)
+  else
+    call rad%radiate(T_surface, T, P, densities, dz, err=err)
+  endif
+  call check()
+  print*, rad%wrk_sol%fdn_n(nz+1)*1.0e-3_dp   ! tests/test_radtran.f90:73
+
+  ! the RCE-Jacobian call pattern (src/adiabat/clima_adiabat_solve.f90:811-812):
+  ! IR only, opacities reused -- results must not change
+  if (np > 0) then
+    call rad%TOA_fluxes(T_surface, T, P, densities, dz, pdensities, radii, compute_solar=.false., &
+                        compute_opacity=.false., ISR=ISR, OLR=OLR, err=err)
+  else
+    call rad%TOA_fluxes(T_surface, T, P, densities, dz, compute_solar=.false., compute_opacity=.false., &
+                        ISR=ISR, OLR=OLR, err=err)
+  endif
+  call check()
+
+  open(newunit=u, file=trim(fout), status='replace')
+  write(u,'(2es26.17e3)') ISR, OLR
+  write(u,'(es26.17e3)') rad%wrk_ir%fup_n
+  write(u,'(es26.17e3)') rad%wrk_sol%fdn_n
+  write(u,'(es26.17e3)') rad%f_total
+  write(u,'(es26.17e3)') rad%wrk_ir%fup_a(nz+1,:)   ! tests/test_radtran.f90:77
+  write(u,'(es26.17e3)') rad%wrk_sol%fup_a(nz+1,:)  ! :79
+  close(u)
+
+  ! error convention: allocated err <=> failure, reference message text
+  if (np > 0) then
+    call rad%radiate(T_surface, T(1:nz-1), P, densities, dz, pdensities, radii, err=err)
+  else
+    call rad%radiate(T_surface, T(1:nz-1), P, densities, dz, err=err)
+  endif
+  if (.not. allocated(err)) then
+    print*, 'expected a dimension error'
+    stop 1
+  endif
+  write(output_unit,'(a)') 'expected error: '//err
+  call rad%destroy()
+
+contains
+  subroutine check()
+    if (allocated(err)) then
+      print*, err
+      stop 1
+    endif
+  end subroutine
+end program

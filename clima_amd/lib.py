@@ -38,6 +38,7 @@ SIGNATURES = {
     "radtran_synchronize": [_vp, _err],
     "radtran_flux_device_ptr": [_vp, _vpp, _ip],
     "radtran_set_bin_shard": [_vp, _ip, _ip, _err],
+    "radtran_bin_shard_get": [_vp, _ip, _ip, _ip, _ip, _ip, _ip],
     "radtran_finish_reduced": [_vp, _err],
     "radtran_stream_get": [_vp, _vpp],
     "radtran_profile_set": [_vp, _ip],
@@ -105,6 +106,13 @@ def load():
             raise ImportError(
                 "clima_amd: HIP extension %s is missing. Build it with "
                 "`python -m clima_amd.build` (hipcc, gfx950); there is no CPU fallback." % LIB_PATH)
+        # PyTorch (device memory, streams, torch.distributed plumbing) bundles its own
+        # libamdhip64.so.7; importing it first makes this library bind to the same HIP
+        # runtime, so device pointers and the current device are shared with torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -227,6 +227,22 @@ class Radtran:
         self._L.radtran_set_bin_shard(self._ptr, _i(rank), _i(world), self._err)
         self._check()
 
+    def bin_shard(self):
+        v = [C.c_int() for _ in range(6)]
+        self._L.radtran_bin_shard_get(self._ptr, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
+    def flux_tensor(self):
+        """The packed level fluxes [ir_up, ir_dn, sol_up, sol_dn][nz+1] as a torch CUDA tensor
+        aliasing the library's buffer (the RCCL all-reduce payload of a bin-sharded run)."""
+        import torch
+        ptr, n = self.flux_device_ptr()
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_Alias(), device="cuda")
+
     def finish_reduced(self):
         self._L.radtran_finish_reduced(self._ptr, self._err)
         self._check()

@@ -117,6 +117,10 @@ void radtran_flux_device_ptr(void *ptr, void **dptr, int *count);
 /* restrict this handle to opacity bins of shard `rank` out of `world` (work-balanced
  * contiguous ranges; rank 0-based).  world=1 restores the full grid. */
 void radtran_set_bin_shard(void *ptr, const int *rank, const int *world, char *err);
+/* the ranges this handle owns: first opacity bin / count (0-based), then the channel-local
+ * IR and solar sub-ranges */
+void radtran_bin_shard_get(void *ptr, int *op_lo, int *op_n, int *ir_lo, int *ir_n, int *sol_lo,
+                           int *sol_n);
 /* after an external all-reduce of the flux buffer: recompute f_total on the device */
 void radtran_finish_reduced(void *ptr, char *err);
 /* HIP stream the handle launches on (for callers that order other work against it) */

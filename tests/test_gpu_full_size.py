@@ -1,0 +1,103 @@
+"""BASELINE.json's full-size configuration (200 layers, 1000 bins, 8 g-points, 8 zenith
+angles) -- checked against the oracle once, and through size-independent properties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nominal():
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    tb = S.modern_earth_tables()
+    return tb, Radtran(tb, 200, 8, 0.15), S.modern_earth_column(200)
+
+
+def test_config2_olr_against_oracle(O, nominal):
+    tb, r, col = nominal
+    o = O.OracleRadtran(tb, 200, 8, 0.15)
+    isr_o, olr_o = o.TOA_fluxes(*col.args())
+    isr, olr = r.TOA_fluxes(*col.args())
+    assert abs(olr - olr_o) <= 1e-9 * abs(olr_o)          # north_star: 1e-4
+    assert abs(isr - isr_o) <= 1e-9 * abs(isr_o)
+    albedo = r.wrk_sol.fup_n[-1] / r.wrk_sol.fdn_n[-1]
+    albedo_o = o.wrk_sol.fup_n[-1] / o.wrk_sol.fdn_n[-1]
+    assert abs(albedo - albedo_o) <= 1e-9 * albedo_o
+    for wg, wo in ((r.wrk_ir, o.wrk_ir), (r.wrk_sol, o.wrk_sol)):
+        for a, b in ((wg.fup_n, wo.fup_n), (wg.fdn_n, wo.fdn_n)):
+            assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b))
+        for a, b in ((wg.fup_a, wo.fup_a), (wg.fdn_a, wo.fdn_a), (wg.amean, wo.amean)):
+            assert np.max(np.abs(a - b)) <= 1e-8 * max(np.max(np.abs(b)), 1e-300)
+
+
+def test_solar_is_linear_in_the_stellar_flux(nominal):
+    tb, r, col = nominal
+    r.photon_scale_factor = 1.0
+    r.radiate(*col.args())
+    base_up, base_dn, ir_up = r.wrk_sol.fup_n, r.wrk_sol.fdn_n, r.wrk_ir.fup_n
+    r.photon_scale_factor = 0.25
+    r.radiate(*col.args(), compute_opacity=False)
+    assert np.allclose(r.wrk_sol.fup_n, 0.25 * base_up, rtol=1e-13)
+    assert np.allclose(r.wrk_sol.fdn_n, 0.25 * base_dn, rtol=1e-13)
+    assert np.array_equal(r.wrk_ir.fup_n, ir_up)           # the IR does not see the star
+    r.photon_scale_factor = 1.0
+
+
+def test_integrals_are_sums_of_the_spectra(nominal):
+    tb, r, col = nominal
+    r.radiate(*col.args())
+    for w, ch in ((r.wrk_ir, r.ir), (r.wrk_sol, r.sol)):
+        dfreq = ch.freq[:-1] - ch.freq[1:]
+        assert np.allclose(w.fup_n, w.fup_a @ dfreq, rtol=1e-12)
+        assert np.allclose(w.fdn_n, w.fdn_a @ dfreq, rtol=1e-12)
+    f = r.f_total
+    assert np.allclose(f, (r.wrk_sol.fdn_n - r.wrk_sol.fup_n) + (r.wrk_ir.fdn_n - r.wrk_ir.fup_n), rtol=1e-13,
+                       atol=1e-9)
+
+
+def test_energy_conservation_of_conservative_limits(nominal):
+    tb, r, col = nominal
+    r.radiate(*col.args())
+    sol = r.wrk_sol
+    # net solar flux decreases monotonically downward (absorption only removes energy)
+    net = sol.fdn_n - sol.fup_n
+    assert np.all(np.diff(net) >= -1e-9 * net[-1])
+    # nothing comes down in the thermal at the top; up-flux at the ground is the Planck surface term
+    assert r.wrk_ir.fdn_n[-1] == 0.0
+    assert 0 < sol.fup_n[-1] < sol.fdn_n[-1]
+
+
+def test_repeatability_and_resident_path(nominal):
+    tb, r, col = nominal
+    a = r.TOA_fluxes(*col.args())
+    b = r.TOA_fluxes(*col.args())
+    assert a == b                                           # bitwise repeatable
+    r.upload_column(*col.args())
+    r.radiate_resident()
+    r.synchronize()
+    assert -(r.wrk_ir.fdn_n[-1] - r.wrk_ir.fup_n[-1]) == a[1]
+
+
+def test_bin_sharded_partials_add_up(nominal):
+    """config 5 mechanics on one GPU: every shard's partial level fluxes sum to the whole."""
+    from clima_amd.sharding import bin_shard
+    tb, r, col = nominal
+    r.radiate(*col.args())
+    full = np.stack([r.wrk_ir.fup_n, r.wrk_ir.fdn_n, r.wrk_sol.fup_n, r.wrk_sol.fdn_n])
+    world = 4
+    acc = np.zeros_like(full)
+    ir0 = int(np.argmin(np.abs(tb.wavl - tb.ir_wavl[0])))
+    nw_ir, nw_sol = len(tb.ir_wavl) - 1, len(tb.sol_wavl) - 1
+    covered = 0
+    for rank in range(world):
+        r.set_bin_shard(rank, world)
+        assert r.bin_shard() == bin_shard(tb.nw, (ir0, ir0 + nw_ir - 1), (0, nw_sol - 1), 8, rank, world)
+        covered += r.bin_shard()[1]
+        r.upload_column(*col.args())
+        r.radiate_resident()
+        r.synchronize()
+        acc += np.stack([r.wrk_ir.fup_n, r.wrk_ir.fdn_n, r.wrk_sol.fup_n, r.wrk_sol.fdn_n])
+    r.set_bin_shard(0, 1)
+    assert covered == tb.nw
+    assert np.allclose(acc, full, rtol=1e-12, atol=1e-9)

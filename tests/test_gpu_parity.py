@@ -1,0 +1,225 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Floating-point path: tolerances are stated here.
+
+north_star tolerance: OLR within 1e-4 relative of the reference.  What is enforced:
+  * OLR / ISR ............................ 1e-9 relative
+  * level fluxes fup_n, fdn_n, f_total .... 1e-9 of the profile maximum
+  * per-bin spectra fup_a, fdn_a, amean ... 1e-8 of the array maximum
+  * opr tau, w0, g, tau_band .............. 1e-11 relative (k-table exp() argument rounding
+    bounds this at ~3e-14; measured 2.8e-14)
+Differences come from device exp/log10 (<=1 ulp), FMA contraction, reciprocal-multiply in
+the chunked Thomas sweeps, and the summation order of the zenith/g-point weights.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL_TOA = 1e-9
+TOL_LEVEL = 1e-9
+TOL_SPEC = 1e-8
+RTOL_OPR = 1e-11
+
+
+def _rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def _scaled(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def _pair(O, tables, nz, nzen, albedo, **scalars):
+    from clima_amd.radtran import Radtran
+    r = Radtran(tables, nz, nzen, albedo)
+    o = O.OracleRadtran(tables, nz, nzen, albedo)
+    for k, v in scalars.items():
+        setattr(r, k, v)
+    if scalars:
+        o.set_scalars(**scalars)
+    return r, o
+
+
+def _compare(r, o, col, **kw):
+    isr, olr = r.TOA_fluxes(*col.args(), **kw)
+    isr_o, olr_o = o.TOA_fluxes(*col.args(), **kw)
+    assert abs(olr - olr_o) <= RTOL_TOA * abs(olr_o)
+    assert abs(isr - isr_o) <= RTOL_TOA * max(abs(isr_o), 1e-300)
+    for wg, wo in ((r.wrk_ir, o.wrk_ir), (r.wrk_sol, o.wrk_sol)):
+        assert _scaled(wg.fup_n, wo.fup_n) <= TOL_LEVEL
+        assert _scaled(wg.fdn_n, wo.fdn_n) <= TOL_LEVEL
+        assert _scaled(wg.fup_a, wo.fup_a) <= TOL_SPEC
+        assert _scaled(wg.fdn_a, wo.fdn_a) <= TOL_SPEC
+        assert _scaled(wg.amean, wo.amean) <= TOL_SPEC
+        assert _rel(wg.tau_band, wo.tau_band) <= RTOL_OPR
+    assert _scaled(r.f_total, o.f_total) <= TOL_LEVEL
+    for a, b in zip(r.opr(), o.opr()):
+        assert _rel(a, b) <= RTOL_OPR
+    return isr, olr
+
+
+def test_hip_extension_is_loaded(hip_lib):
+    """The tests below run the in-tree HIP library, not a fallback."""
+    import os
+    from clima_amd import lib
+    maps = open("/proc/%d/maps" % os.getpid()).read()
+    assert os.path.basename(lib.LIB_PATH) in maps
+
+
+def test_config1_modern_earth_50_layers(O, small_tables):
+    # BASELINE.json configs[0]: ModernEarth, 50 layers, 1 zenith angle, albedo 0.3
+    from clima_amd import synthetic as S
+    r, o = _pair(O, small_tables, 50, 1, 0.3)
+    _compare(r, o, S.modern_earth_column(50))
+
+
+@pytest.mark.parametrize("nz", [1, 2, 3, 5, 16, 63, 64, 65])
+def test_layer_counts_and_chunk_edges(O, nz):
+    # ragged sizes around the wave width and the chunked solve's boundaries
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=10, seed=100 + nz)
+    r, o = _pair(O, tb, nz, 2, 0.25)
+    _compare(r, o, S.modern_earth_column(nz))
+
+
+def test_multiple_zenith_angles_and_scalars(O, small_tables):
+    from clima_amd import synthetic as S
+    r, o = _pair(O, small_tables, 40, 8, 0.15, photon_scale_factor=0.4286, diurnal_fac=0.37)
+    _compare(r, o, S.modern_earth_column(40))
+
+
+def test_no_hard_surface_and_emissivity(O, small_tables):
+    from clima_amd import synthetic as S
+    r, o = _pair(O, small_tables, 30, 2, 0.2, has_hard_surface=False, ir_tau_min=1e-3)
+    _compare(r, o, S.modern_earth_column(30))
+    r2, o2 = _pair(O, small_tables, 30, 2, 0.2)
+    em = np.linspace(0.6, 1.0, len(r2.surface_emissivity))
+    al = np.linspace(0.0, 0.9, len(r2.surface_albedo))
+    r2.surface_emissivity = em
+    r2.surface_albedo = al
+    o2.set_surface_emissivity(em)
+    o2.set_surface_albedo(al)
+    _compare(r2, o2, S.modern_earth_column(30))
+
+
+def test_pair_reuse_doubled_grid(O, small_tables):
+    # AdiabatClimate's doubled radiative grid: identical layer pairs (types.f90:621-632)
+    from clima_amd import synthetic as S
+    col = S.doubled_column(S.modern_earth_column(32))
+    r, o = _pair(O, small_tables, 64, 4, 0.3)
+    _compare(r, o, col)
+    # pairs equal only to 1e-13 still count as reusable; the second layer copies the first
+    col2 = S.doubled_column(S.modern_earth_column(32))
+    col2["T"][1::2] *= 1 + 1e-13
+    _compare(r, o, col2)
+
+
+def test_unsorted_k_coefficients_use_full_network(O):
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=24, sorted_k=False, seed=11)
+    r, o = _pair(O, tb, 31, 3, 0.1)
+    _compare(r, o, S.modern_earth_column(31))
+
+
+def test_ties_and_zero_columns(O, small_tables):
+    # a species with zero abundance gives 8-fold ties in every resort
+    from clima_amd import synthetic as S
+    col = S.modern_earth_column(20)
+    col["densities"][:, 1] = 0.0      # CO2 absent
+    col["densities"][:, 4] = 0.0      # O3 absent
+    r, o = _pair(O, small_tables, 20, 2, 0.3)
+    _compare(r, o, col)
+
+
+def test_single_k_species_no_resort(O):
+    # nk = 1: the RORR loop is never entered (types.f90:823)
+    from clima_amd import synthetic as S
+    tb = S.make_tables(nw=16, k_species=("H2O",), seed=5)
+    r, o = _pair(O, tb, 25, 2, 0.3)
+    _compare(r, o, S.modern_earth_column(25))
+
+
+def test_early_mars_cia_heavy(O):
+    # BASELINE.json configs[2] at reduced bin count
+    from clima_amd import synthetic as S
+    tb = S.early_mars_tables(nw=60)
+    r, o = _pair(O, tb, 200, 4, 0.2, photon_scale_factor=0.4286)
+    _compare(r, o, S.early_mars_column(200))
+
+
+def test_state_carried_between_calls(O, small_tables):
+    # compute_opacity=False reuses opr; compute_solar=False reuses wrk_sol (clima_radtran.f90:255-289)
+    from clima_amd import synthetic as S
+    col = S.modern_earth_column(50)
+    r, o = _pair(O, small_tables, 50, 2, 0.3)
+    _compare(r, o, col)
+    warm = S.Column(col)
+    warm["T"] = col["T"] + 3.0
+    warm["T_surface"] = col["T_surface"] + 3.0
+    _compare(r, o, warm, compute_solar=False, compute_opacity=False)   # the RCE-Jacobian call pattern
+    _compare(r, o, warm, compute_solar=False)
+    _compare(r, o, warm)
+
+
+def test_radiation_enhancement_and_bolometric(O, small_tables):
+    from clima_amd import synthetic as S
+    col = S.modern_earth_column(50)
+    r, o = _pair(O, small_tables, 50, 2, 0.3)
+    r.radiate(*col.args())
+    sol = r.wrk_sol
+    fup_n, fdn_a = sol.fup_n, sol.fdn_a
+    ir = r.wrk_ir
+    r.apply_radiation_enhancement(1.7)
+    assert np.allclose(r.wrk_sol.fup_n, fup_n * 1.7, rtol=1e-15)
+    assert np.allclose(r.wrk_sol.fdn_a, fdn_a * 1.7, rtol=1e-15)
+    s2 = r.wrk_sol
+    assert np.allclose(r.f_total, (s2.fdn_n - s2.fup_n) + (ir.fdn_n - ir.fup_n), rtol=1e-15)
+    flux = r.bolometric_flux()
+    ps, fr = r.photons_sol, r.sol.freq
+    assert abs(flux - np.sum(ps * (fr[:-1] - fr[1:])) / 1e3) <= 1e-12 * flux
+    r.set_bolometric_flux(1000.0)
+    assert abs(r.bolometric_flux() - 1000.0) < 1e-9
+    assert abs(r.equilibrium_temperature(0.3) - (1000.0 * 0.7 / (4 * 5.670374419e-8)) ** 0.25) < 1e-9
+    assert abs(r.skin_temperature(0.3) - r.equilibrium_temperature(0.3) * 0.5 ** 0.25) < 1e-9
+
+
+def test_error_behaviour_matches_reference(small_tables):
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import ClimaException, Radtran
+    col = S.modern_earth_column(50)
+    r = Radtran(small_tables, 50, 1, 0.3)
+    with pytest.raises(ClimaException, match="The model contains particles"):
+        r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"])
+    with pytest.raises(ClimaException, match='"T" has the wrong input dimension.'):
+        r.radiate(col["T_surface"], col["T"][:-1], col["P"], col["densities"], col["dz"], col["pdensities"],
+                  col["radii"])
+    with pytest.raises(ClimaException, match='"densities" has the wrong input dimension.'):
+        r.radiate(col["T_surface"], col["T"], col["P"], col["densities"][:, :-1], col["dz"], col["pdensities"],
+                  col["radii"])
+    with pytest.raises(ClimaException, match="Both pdensities and radii must be arguments."):
+        r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"], col["pdensities"], None)
+    # particle radius outside the Mie grid -> every bin flags ierr (types.f90:973-976, :773-776)
+    with pytest.raises(ClimaException, match="Opacity computation failed in one or more wavelength bins."):
+        r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"], col["pdensities"],
+                  col["radii"] * 1e6)
+    r.radiate(*col.args())   # and the handle recovers
+    with pytest.raises(ClimaException, match="is the wrong size"):
+        r.zenith_u = np.ones(3)
+
+
+def test_accessor_shapes_and_channels(small_tables):
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    r = Radtran(small_tables, 50, 4, 0.3)
+    r.radiate(*S.modern_earth_column(50).args())
+    nw_ir, nw_sol = len(small_tables.ir_wavl) - 1, len(small_tables.sol_wavl) - 1
+    assert r.wrk_ir.fup_a.shape == (51, nw_ir) and r.wrk_ir.fup_a.flags.f_contiguous
+    assert r.wrk_sol.amean.shape == (51, nw_sol) and r.wrk_sol.tau_band.shape == (50, nw_sol)
+    assert np.all(r.wrk_ir.amean == 0.0)                                   # clima_radtran.f90:205
+    assert np.array_equal(r.ir.wavl, small_tables.ir_wavl) and len(r.sol.freq) == nw_sol + 1
+    assert np.allclose(r.ir.freq, 299792458.0 / (r.ir.wavl * 1e-9), rtol=1e-15)
+    u = r.zenith_u
+    assert len(u) == 4 and np.all((u > 0) & (u < 1)) and abs(np.sum(r.zenith_weights) - 1) < 1e-14
+    assert r.f_total.shape == (51,)

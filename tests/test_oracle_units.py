@@ -1,0 +1,94 @@
+"""Unit-level checks of the oracle restatement against first-principles definitions
+(the parts of the path the reference has no fixtures for)."""
+import numpy as np
+import pytest
+
+
+def test_bracket_semantics_1d(O):
+    # dintrv: x<xt(1)->(1,2) extrapolate; xt(i)<=x<xt(i+1)->(i,i+1); x>=xt(n)->(n-1,n)
+    # (linear_interpolation_module.F90:348-350)
+    x = np.array([1.0, 2.0, 4.0, 8.0])
+    f = np.array([10.0, 20.0, 0.0, -8.0])
+    assert O.interp1d(x, f, 1.0) == 10.0
+    assert O.interp1d(x, f, 2.0) == 20.0           # node belongs to the right interval
+    assert O.interp1d(x, f, 3.0) == 10.0
+    assert O.interp1d(x, f, 8.0) == -8.0           # last node: q = 1 on the last interval
+    assert O.interp1d(x, f, 0.0) == 0.0            # linear extrapolation on (1,2)
+    assert O.interp1d(x, f, 12.0) == -16.0         # and on (n-1,n)
+
+
+def test_interp2d_matches_scipy(O):
+    from scipy.interpolate import RegularGridInterpolator
+    rng = np.random.default_rng(0)
+    x, y = np.sort(rng.uniform(-6, 2, 9)), np.sort(rng.uniform(50, 900, 7))
+    f = rng.normal(size=(9, 7))
+    ref = RegularGridInterpolator((x, y), f)
+    for _ in range(200):
+        xv, yv = rng.uniform(x[0], x[-1]), rng.uniform(y[0], y[-1])
+        assert abs(O.interp2d(x, y, f, xv, yv) - ref([[xv, yv]])[0]) < 1e-12
+
+
+def test_mrgrnk_is_stable_ascending_rank(O):
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        v = rng.integers(0, 8, 64).astype(float)     # many ties
+        r = O.mrgrnk(v)
+        assert sorted(r.tolist()) == list(range(64))
+        assert np.array_equal(r, np.argsort(v, kind="stable"))
+
+
+def test_rebin_is_conservative(O):
+    rng = np.random.default_rng(2)
+    w = rng.uniform(0.1, 1, 64)
+    edges = np.concatenate([[0], np.cumsum(w)]) / w.sum()
+    vals = np.sort(rng.uniform(0, 5, 64))
+    new = np.concatenate([[0], np.cumsum(rng.uniform(0.5, 1, 8))])
+    new = new / new[-1]
+    out = O.rebin(edges, vals, new)
+    assert abs(np.sum(out * np.diff(new)) - np.sum(vals * np.diff(edges))) < 1e-13
+    assert np.all(np.diff(out) >= -1e-15)            # means of a sorted step function stay sorted
+    # identical grids: identity
+    assert np.allclose(O.rebin(edges, vals, edges), vals, rtol=1e-13)
+
+
+def test_planck_and_ten2power(O):
+    h, c, k = 6.62607004e-34, 299792458.0, 1.380649e-23
+    nu, T = 3.0e13, 288.0
+    ref = 1.0e3 * 2 * h * nu ** 3 / c ** 2 / np.expm1(h * nu / (k * T))
+    assert abs(O.planck_fcn(nu, T) / ref - 1) < 1e-13
+    assert abs(O.lib().orc_ten2power(-20.5) / 10 ** -20.5 - 1) < 1e-14
+
+
+def test_gauss_legendre(O):
+    for n in (1, 2, 4, 8):
+        x, w = O.gauss_legendre(n)
+        xr, wr = np.polynomial.legendre.leggauss(n)
+        assert np.allclose(x, xr, atol=1e-15) and np.allclose(w, wr, atol=1e-15)
+
+
+def test_radiate_sanity_and_flags(O, small_tables):
+    from clima_amd import synthetic as S
+    col = S.modern_earth_column(50)
+    r = O.OracleRadtran(small_tables, 50, 4, 0.3)
+    isr, olr = r.TOA_fluxes(*col.args())
+    assert 200e3 < olr < 300e3 and 200e3 < isr < 345e3
+    ir, sol = r.wrk_ir, r.wrk_sol
+    assert np.all(ir.fdn_n[-1] == 0.0)                               # no downward IR at TOA (:289)
+    assert np.allclose(r.f_total, (sol.fdn_n - sol.fup_n) + (ir.fdn_n - ir.fup_n), rtol=0, atol=0)
+    # compute_solar=False keeps wrk_sol (clima_radtran.f90:286-289)
+    sol_before = sol.fup_n.copy()
+    r.radiate(col["T_surface"] + 5, col["T"] + 5, col["P"], col["densities"], col["dz"], col["pdensities"],
+              col["radii"], compute_solar=False)
+    assert np.array_equal(r.wrk_sol.fup_n, sol_before)
+    assert r.TOA_fluxes(*col.args())[1] == olr                        # deterministic
+
+
+def test_oracle_error_texts(O, small_tables):
+    from clima_amd import synthetic as S
+    col = S.modern_earth_column(50)
+    r = O.OracleRadtran(small_tables, 50, 1, 0.3)
+    with pytest.raises(O.OracleError, match="The model contains particles"):
+        r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"])
+    bad = col["radii"] * 1e6                                          # outside the Mie grid: ierr (:973-976)
+    with pytest.raises(O.OracleError, match="Opacity computation failed in one or more wavelength bins."):
+        r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"], col["pdensities"], bad)
