@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
     if (sl.source == 0) x = log10(c.P[js]);
     else if (sl.source == 1) x = c.T[js];
     else x = c.radii[(sl.source - 2) * nz + js];
-    if (sl.flag_clamp && (x < sl.lo || x > sl.hi)) atomicOr(c.err_flag, 1);
+    if (sl.flag_clamp && (x < sl.lo || x > sl.hi)) atomicMax(c.err_flag, p.call_id);  // stamped, never reset
     x = fmin(fmax(x, sl.lo), sl.hi);  // :655-656, :910, :937, :974
     const int i = bracket(axis, sl.n, x);
     c.ix[s * nz + j] = i;
@@ -834,6 +834,17 @@ __global__ __launch_bounds__(MAXT, MINW) void k_twostream(TwoStreamParams p) {
   }
 }
 
+struct ZeroParams {
+  double *ptr[6];
+  size_t count[6];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_zero(ZeroParams z) {
+  double *p = z.ptr[blockIdx.y];
+  const size_t n = z.count[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+
 // LDS bytes for nc columns per block
 static size_t ts_lds_bytes(int nz, int nc, int S) {
   return sizeof(double) * ((size_t)6 * nz * nc + (nz + 1) + 3 * nc + (size_t)((nz + 7) / 8) * nc + (size_t)6 * S * nc + (size_t)(nz + 2) / 2 + 1);
@@ -873,17 +884,20 @@ bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
   const int grid = p.n_sol + p.n_ir;
   if (grid <= 0) return true;
   const dim3 g(grid, p.ng / nc);
-  if (g.y > 1) {  // partial sums over g-point groups accumulate into zeroed outputs
+  if (g.y > 1) {  // partial sums over g-point groups accumulate into zeroed outputs: one launch
     const size_t nl = (size_t)p.nz + 1;
+    ZeroParams z;
+    z.n = 0;
     if (p.n_ir > 0) {
-      (void)hipMemsetAsync(p.ir_fup_a + (size_t)p.ir_lo * nl, 0, sizeof(double) * nl * p.n_ir, s);
-      (void)hipMemsetAsync(p.ir_fdn_a + (size_t)p.ir_lo * nl, 0, sizeof(double) * nl * p.n_ir, s);
+      z.ptr[z.n] = p.ir_fup_a + (size_t)p.ir_lo * nl; z.count[z.n++] = nl * p.n_ir;
+      z.ptr[z.n] = p.ir_fdn_a + (size_t)p.ir_lo * nl; z.count[z.n++] = nl * p.n_ir;
     }
     if (p.n_sol > 0) {
-      (void)hipMemsetAsync(p.sol_fup_a + (size_t)p.sol_lo * nl, 0, sizeof(double) * nl * p.n_sol, s);
-      (void)hipMemsetAsync(p.sol_fdn_a + (size_t)p.sol_lo * nl, 0, sizeof(double) * nl * p.n_sol, s);
-      (void)hipMemsetAsync(p.sol_amean + (size_t)p.sol_lo * nl, 0, sizeof(double) * nl * p.n_sol, s);
+      z.ptr[z.n] = p.sol_fup_a + (size_t)p.sol_lo * nl; z.count[z.n++] = nl * p.n_sol;
+      z.ptr[z.n] = p.sol_fdn_a + (size_t)p.sol_lo * nl; z.count[z.n++] = nl * p.n_sol;
+      z.ptr[z.n] = p.sol_amean + (size_t)p.sol_lo * nl; z.count[z.n++] = nl * p.n_sol;
     }
+    if (z.n > 0) hipLaunchKernelGGL(k_zero, dim3(128, z.n), dim3(256), 0, s, z);
   }
   if (threads <= 512) {
     static bool attr512 = false;

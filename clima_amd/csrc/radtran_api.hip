@@ -130,6 +130,7 @@ struct Radtran {
   size_t col_count = 0;
   bool column_has_particles = false;
   bool column_loaded = false;
+  int call_id = 0, checked_id = 0;  // opacity passes enqueued / already checked for device errors
   std::vector<double> last_T, last_P, last_radii;  // host copy for byte accounting
   // opr
   DevBuf<double> d_tau, d_w0, d_g, d_tau_band;
@@ -351,7 +352,6 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   const int nz = r->nz;
   ColumnDev col = column_dev(r);
   if (compute_opacity) {
-    HIPCHK(hipMemsetAsync(r->d_err.p, 0, sizeof(int), r->stream));
     PrepParams pp;
     std::memset(&pp, 0, sizeof(pp));
     pp.nz = nz; pp.nsp = r->nsp; pp.np = r->np; pp.nslots = r->nslots;
@@ -359,6 +359,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     pp.check_radii = (r->column_has_particles && !r->part.empty()) ? 1 : 0;  // types.f90:628
     for (int s = 0; s < r->nslots; s++) pp.slots[s] = r->slots[s];
     pp.col = col;
+    pp.call_id = ++r->call_id;
     { KernelTimer t(r, 0); launch_prep(pp, r->stream); t.stop(); }
 
     OpacityParams op;
@@ -491,7 +492,9 @@ void do_upload(Radtran *r, double T_surface, const double *T, const double *P, c
 }
 
 bool surface_device_error(Radtran *r, char *err) {
-  if (*r->h_errflag != 0) {
+  const bool failed = *r->h_errflag > r->checked_id;  // a call since the last check flagged
+  r->checked_id = r->call_id;
+  if (failed) {
     // clima_radtran_types.f90:773-776
     set_err(err, "Opacity computation failed in one or more wavelength bins.");
     return true;

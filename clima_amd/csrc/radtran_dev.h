@@ -72,7 +72,7 @@ struct ColumnDev {
   int *src;        // source layer for interpolation (j, or j-1 under pair_reuse)
   int *ix;         // [nslots][nz]
   double *q;       // [nslots][nz]
-  int *err_flag;   // device error word (bit 0: particle radius clamp)
+  int *err_flag;   // device error word: id of the last call that clamped a particle radius
   const double *T_surface;  // device scalar
 };
 
@@ -92,6 +92,7 @@ struct OpacityParams {
 
 struct PrepParams {
   int nz, nsp, np, nslots, has_cont, LH2O, check_radii;
+  int call_id;  // stamped into err_flag by a failing call (monotonic, so the flag never needs a reset)
   SlotDev slots[MAX_SLOTS];
   ColumnDev col;
 };
