@@ -104,6 +104,16 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
       }
       c.foreign_col[j] = fc;
       c.src[j] = reuse_source(p, j);
+      // bin-independent weights of the continuum terms (types.f90:696-723)
+      for (int e = 0; e < p.nabs; e++) {
+        const int a = p.abs_a[e], b = p.abs_b[e];
+        double w;
+        if (p.abs_kind[e] == ABS_CIA) w = c.dens[a * nz + j] * c.dens[b * nz + j] * c.dz[j];
+        else if (p.abs_kind[e] == ABS_COLUMN) w = c.dens[a * nz + j] * c.dz[j];
+        else if (p.abs_kind[e] == ABS_H2O_SELF) w = c.dens[a * nz + j] * (c.dens[a * nz + j] * c.dz[j]);
+        else w = c.dens[a * nz + j] * fc;
+        c.absw[e * nz + j] = w;
+      }
     }
     return;
   }
@@ -148,40 +158,37 @@ __device__ __forceinline__ double lerp1(const double *f, int i, double q) {
 constexpr int OP_THREADS = 256;
 
 // Random-overlap resort + rebin for NG = 8 (k_rorr, types.f90:826-852), one lane per
-// (bin, layer).  X = current mixture tau_k(8) and Y = new species' k*col (8) live in the
-// lane's private LDS slots sm[slot][tid] (slot-major: conflict-free for any per-lane
-// slot).  The 64 sums X_i+Y_j are sorted by a Batcher odd-even merge network held in
-// registers (one v_min_f64 + one v_max_f64 per compare-exchange).  Each key carries its
-// pair index in the 6 low mantissa bits -- that orders ties exactly like the stable rank
-// on (value,index) whenever two values differ above 2^-46 relative -- and the exact value
-// is re-formed from X,Y when the key is consumed.  When Y is already ascending (the normal
+// (bin, layer).  x = current mixture tau_k(8), y = new species' k*col (8), in registers.
+// The 64 sums x_i+y_j are sorted by a Batcher odd-even merge network held in registers
+// (one v_min_f64 + one v_max_f64 per compare-exchange).  Each key carries its pair index
+// in the 6 low mantissa bits: that orders ties exactly like the stable rank on
+// (value,index) whenever two values differ above 2^-46 relative, and it is how the sorted
+// stream finds its weight wxy(idx).  The value used downstream is the key with those bits
+// cleared (relative perturbation <= 2^-46 = 1.4e-14, below the 3e-14 that the exp() argument
+// rounding of the k-table interpolation already carries).  When y is ascending (the normal
 // case for k-distributions) the 8 runs of 8 keys are pre-sorted and only the merge tail of
 // the network runs.
-// Rebin (weights_to_bins + futils rebin, types.f90:846-847): with c the running sum of
-// the sorted weights, the integral of the sorted step function up to each output edge
-// E_k is accumulated branch-free, I_k += v*(min(c1,E_k) - min(c0,E_k)); the new
-// coefficients are (I_k - I_{k-1}) / (E_k - E_{k-1}).
-__device__ __forceinline__ void rorr_mix8(double (*sm)[OP_THREADS], const int tid, const int xo,
-                                          const int yo, const double *s_wxy, const double *E,
-                                          double *out) {
+// Rebin (weights_to_bins + futils rebin, types.f90:846-847) as a stream over the sorted
+// keys: c = running sum of the sorted weights, S = running integral of the sorted step
+// function; whenever c passes an output edge E_k the integral up to that edge,
+// I_k = S + v*(E_k - c0), is written to the lane's private LDS slot k.  The new coefficients
+// are (I_k - I_{k-1}) / (E_k - E_{k-1}).
+__device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y)[8],
+                                          double (*sI)[OP_THREADS], const int tid,
+                                          const double *s_wxy, const double *gE,
+                                          const double (&E)[9], double (&out)[8]) {
   double key[64];
   bool ysorted = true;
-  {
-    double y[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) y[j] = sm[yo + j][tid];
+  for (int j = 0; j < 7; j++) ysorted = ysorted && (y[j] <= y[j + 1]);
 #pragma unroll
-    for (int j = 0; j < 7; j++) ysorted = ysorted && (y[j] <= y[j + 1]);
+  for (int i = 0; i < 8; i++) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const double xi = sm[xo + i][tid];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const double v = xi + y[j];  // tau_xy(:, j+(i-1)*ng), types.f90:828
-        unsigned long long b = (unsigned long long)__double_as_longlong(v);
-        b = (b & ~63ULL) | (unsigned long long)(i * 8 + j);
-        key[i * 8 + j] = __longlong_as_double((long long)b);
-      }
+    for (int j = 0; j < 8; j++) {
+      const double v = x[i] + y[j];  // tau_xy(:, j+(i-1)*ng), types.f90:828
+      unsigned long long b = (unsigned long long)__double_as_longlong(v);
+      b = (b & ~63ULL) | (unsigned long long)(i * 8 + j);
+      key[i * 8 + j] = __longlong_as_double((long long)b);
     }
   }
 #define CE(a, b)                              \
@@ -200,32 +207,41 @@ __device__ __forceinline__ void rorr_mix8(double (*sm)[OP_THREADS], const int ti
 #include "sort_network_64.inc"
 #undef CE_MERGE_TAIL
 #undef CE
-  double I[8], m[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) { I[k] = 0.0; m[k] = 0.0; }
-  double c0 = 0.0;
+  double S = 0.0, c0 = 0.0;
+  int k = 1;                          // next output edge to pass: E[k]
+  double bk = E[1], bn = E[2];        // E[k], E[k+1] (prefetched)
+  // weights_to_bins (clima_eqns.f90:43-54) on wxy(inds); the lookup runs one element ahead
+  double wn = s_wxy[(int)((unsigned long long)__double_as_longlong(key[0]) & 63ULL)];
 #pragma unroll
   for (int p = 0; p < 64; p++) {
-    const unsigned lo32 = (unsigned)((unsigned long long)__double_as_longlong(key[p]) & 0xffffffffULL);
-    const int idx = (int)(lo32 & 63u);
-    const double v = sm[xo + (idx >> 3)][tid] + sm[yo + (idx & 7)][tid];
-    const double c1 = c0 + s_wxy[idx];  // weights_to_bins (clima_eqns.f90:43-54) on wxy(inds)
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const double t = dmin(c1, E[k + 1]);
-      I[k] = __builtin_fma(v, t - m[k], I[k]);
-      m[k] = t;
+    const unsigned long long kb = (unsigned long long)__double_as_longlong(key[p]);
+    const double v = __longlong_as_double((long long)(kb & ~63ULL));
+    const double w = wn;
+    if (p < 63) wn = s_wxy[(int)((unsigned long long)__double_as_longlong(key[p + 1]) & 63ULL)];
+    const double c1 = c0 + w;
+    if (c1 > bk) {                    // this element reaches past E[k]
+      do {
+        sI[k - 1][tid] = __builtin_fma(v, bk - c0, S);
+        k++;
+        bk = bn;
+        bn = gE[k + 1];  // global (vmcnt) on purpose: keeps this lookup off the LDS wait counter
+      } while (c1 > bk);
     }
+    S = __builtin_fma(v, w, S);
     c0 = c1;
   }
-  out[0] = I[0] / (E[1] - E[0]);
+  for (; k <= 8; k++) sI[k - 1][tid] = S;  // edges at or beyond the total weight (rounding)
+  double Ik[8];
 #pragma unroll
-  for (int k = 1; k < 8; k++) out[k] = (I[k] - I[k - 1]) / (E[k + 1] - E[k]);
+  for (int q = 0; q < 8; q++) Ik[q] = sI[q][tid];
+  out[0] = Ik[0] / (E[1] - E[0]);
+#pragma unroll
+  for (int q = 1; q < 8; q++) out[q] = (Ik[q] - Ik[q - 1]) / (E[q + 1] - E[q]);
 }
 
-__global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
+__global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   constexpr int NG = 8;
-  __shared__ double sm[2 * NG][OP_THREADS];  // per-lane private slots: X (0..7), Y (8..15)
+  __shared__ double sI[NG][OP_THREADS];  // per-lane private slots (slot-major: conflict-free)
   __shared__ double s_wxy[NG * NG];
   const int tid = threadIdx.x;
   if (tid < NG * NG) s_wxy[tid] = p.wxy[tid];
@@ -238,44 +254,51 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
 
   const int nz = p.nz;
   const long total = (long)p.nbins * nz;
+  const ColumnDev &c = p.col;
   long t = (long)blockIdx.x * OP_THREADS + tid;
   const bool valid = t < total;
   if (!valid) t = total - 1;
   const int l = p.bin_lo + (int)(t / nz);
   const int j = (int)(t % nz);  // ground-first layer
   const int n = nz - 1 - j;     // TOA-first index (types.f90:690-691, :862-865)
-  const ColumnDev &c = p.col;
   const bool reuse = c.src[j] != j;
   const double dzj = c.dz[j];
 
   // ---- Rayleigh (:686-693)
   double tausg = 0.0;
+#pragma unroll 4
   for (int i = 0; i < p.nray; i++) tausg = tausg + p.ray[i].data[l] * c.cols[p.ray[i].sp1 * nz + j];
-  // ---- CIA (:665-667, :696-704)
+  // ---- continuum absorption: CIA, photolysis/absorption, H2O continuum (:665-677, :696-723).
+  // Entries are processed four at a time with every load of the batch issued before the
+  // first use, so the dependent index -> table round trips overlap instead of queueing.
   double taua = 0.0;
-  for (int i = 0; i < p.ncia; i++) {
-    const XsDev &x = p.cia[i];
-    double s;
-    if (x.dim == 0) s = x.data[l];
-    else s = ten2power(lerp1(x.data + (size_t)l * x.nT, c.ix[x.slot * nz + j], c.q[x.slot * nz + j]));
-    taua = taua + s * c.dens[x.sp1 * nz + j] * c.dens[x.sp2 * nz + j] * dzj;
-  }
-  // ---- photolysis / absorption (:670-672, :707-713)
-  for (int i = 0; i < p.npxs; i++) {
-    const XsDev &x = p.pxs[i];
-    double s;
-    if (x.dim == 0) s = x.data[l];
-    else s = ten2power(lerp1(x.data + (size_t)l * x.nT, c.ix[x.slot * nz + j], c.q[x.slot * nz + j]));
-    taua = taua + s * c.cols[x.sp1 * nz + j];
-  }
-  // ---- water continuum (:675-677, :716-723)
-  if (p.has_cont) {
-    const int ix = c.ix[p.cont_slot * nz + j];
-    const double q = c.q[p.cont_slot * nz + j];
-    const double h2o = ten2power(lerp1(p.cont_H2O + (size_t)l * p.cont_nT, ix, q));
-    const double frn = ten2power(lerp1(p.cont_foreign + (size_t)l * p.cont_nT, ix, q));
-    const double dL = c.dens[p.LH2O * nz + j];
-    taua = taua + h2o * dL * c.cols[p.LH2O * nz + j] + frn * dL * c.foreign_col[j];
+  for (int e0 = 0; e0 < p.nabs; e0 += 4) {
+    int ixx[4];
+    double qq[4], ww[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
+      ixx[u] = c.ix[x.slot * nz + j];
+      qq[u] = c.q[x.slot * nz + j];
+      ww[u] = c.absw[min(e0 + u, p.nabs - 1) * nz + j];
+    }
+    double v0[4], v1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
+      const double *base = x.data + (x.nT ? (size_t)l * x.nT + ixx[u] : (size_t)l);
+      v0[u] = base[0];
+      v1[u] = base[x.nT ? 1 : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (e0 + u < p.nabs) {
+        const AbsEntry &x = p.abs[e0 + u];
+        double sgm = v0[u];
+        if (x.nT) sgm = ten2power((1.0 - qq[u]) * v0[u] + qq[u] * v1[u]);  // lerp1 + ten2power (:910-912)
+        taua = taua + sgm * ww[u];
+      }
+    }
   }
   // ---- custom opacity unset (:558-562, :726-730): tiny everywhere
   const double tauc = TINY, tausc = TINY * TINY;
@@ -301,10 +324,21 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
   gt = fmin(gt, MAX_GT);
 
   // ---- k-distributions (:649-662) and random-overlap mixing (k_rorr :816-854)
+  double tk[NG];  // tau_k of the running mixture
+#pragma unroll
+  for (int g = 0; g < NG; g++) tk[g] = 0.0;
+  // interpolation brackets of the next species are fetched while the current one is mixed
+  int iP_n = c.ix[p.k[0].slotP * nz + j], iT_n = c.ix[p.k[0].slotT * nz + j];
+  double q1_n = c.q[p.k[0].slotP * nz + j], q2_n = c.q[p.k[0].slotT * nz + j];
   for (int s = 0; s < p.nk; s++) {
     const KDev &kd = p.k[s];
-    const int iP = c.ix[kd.slotP * nz + j], iT = c.ix[kd.slotT * nz + j];
-    const double q1 = c.q[kd.slotP * nz + j], q2 = c.q[kd.slotT * nz + j];
+    const int iP = iP_n, iT = iT_n;
+    const double q1 = q1_n, q2 = q2_n;
+    if (s + 1 < p.nk) {
+      const KDev &kn = p.k[s + 1];
+      iP_n = c.ix[kn.slotP * nz + j]; iT_n = c.ix[kn.slotT * nz + j];
+      q1_n = c.q[kn.slotP * nz + j]; q2_n = c.q[kn.slotT * nz + j];
+    }
     const double p1 = 1.0 - q1, p2 = 1.0 - q2;
     const double *slab = kd.log10k + (size_t)l * kd.nT * kd.nP * NG;
     const double *f11 = slab + ((size_t)iT * kd.nP + iP) * NG;
@@ -312,24 +346,26 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
     const double *f12 = f11 + (size_t)kd.nP * NG;    // iT+1
     const double *f22 = f12 + NG;
     const double col = c.cols[kd.sp * nz + j];
-    const int dst = (s == 0) ? 0 : NG;
+    double kc[NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       // linear_interp_2d%evaluate, linear_interpolation_module.F90:319-327
       const double fx1 = p1 * f11[g] + q1 * f21[g];
       const double fx2 = p1 * f12[g] + q1 * f22[g];
-      const double kk = ten2power(p2 * fx1 + q2 * fx2);
-      sm[dst + g][tid] = kk * col;  // :818 / :828
+      kc[g] = ten2power(p2 * fx1 + q2 * fx2) * col;  // :818 / :828
     }
-    if (s > 0 && !(p.debug_skip & 1)) {
+    if (s == 0) {
+#pragma unroll
+      for (int g = 0; g < NG; g++) tk[g] = kc[g];
+    } else if (!(p.debug_skip & 1)) {
       double out[NG];
-      rorr_mix8(sm, tid, 0, NG, s_wxy, E, out);
+      rorr_mix8(tk, kc, sI, tid, s_wxy, p.wbin_e_pad, E, out);
       // pair_reuse: the second layer of a pair copies the first layer's rebinned
       // mixture (:833-834).  Layer j-1 of the same bin lives in lane-1 (nz even).
 #pragma unroll
       for (int g = 0; g < NG; g++) {
         const double prev = __shfl_up(out[g], 1);
-        sm[g][tid] = reuse ? prev : out[g];
+        tk[g] = reuse ? prev : out[g];
       }
     }
   }
@@ -340,7 +376,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity8(OpacityParams p) {
     const size_t base = ((size_t)l * NG) * nz + n;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-      const double tau = tausg + taua + taup + sm[g][tid] + tauc;
+      const double tau = tausg + taua + taup + tk[g] + tauc;
       double w0;
       if (tau <= TAU_MIN) w0 = 0.0;
       else w0 = fmin(MAX_W0, (tausg + tausp + tausc) / tau);

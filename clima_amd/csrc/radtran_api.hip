@@ -104,12 +104,13 @@ struct Radtran {
   std::vector<KTabHost *> k;
   std::vector<XsHost *> cia, ray, pxs;
   std::vector<PartHost *> part;
+  std::vector<int> part_slot;
   bool has_cont = false;
   int LH2O = -1, cont_nT = 0;
   std::vector<double> cont_temp, cont_H2O, cont_foreign;
   DevBuf<double> d_cont_temp, d_cont_H2O, d_cont_foreign;
   std::vector<double> wbin, wbin_e, wxy;
-  DevBuf<double> d_wbin, d_wbin_e, d_wxy, d_freq;
+  DevBuf<double> d_wbin, d_wbin_e, d_wbin_e_pad, d_wxy, d_freq;
   ChannelObj ir, sol;
   WrkObj wrk_ir, wrk_sol;
   // public fields (clima_radtran.f90:51-68)
@@ -124,7 +125,8 @@ struct Radtran {
   int nslots = 0;
   std::vector<SlotDev> slots;
   DevBuf<double> d_col;  // [T_surface | T | P | dz | dens | pdens | radii]
-  DevBuf<double> d_log10P, d_cols, d_foreign, d_q;
+  DevBuf<double> d_log10P, d_cols, d_foreign, d_q, d_absw;
+  std::vector<AbsEntry> abs_entries;  // continuum terms in the reference's summation order
   DevBuf<int> d_src, d_ix, d_err;
   double *h_col = nullptr;  // pinned staging
   size_t col_count = 0;
@@ -340,6 +342,7 @@ ColumnDev column_dev(Radtran *r) {
   c.log10P = r->d_log10P.p;
   c.cols = r->d_cols.p;
   c.foreign_col = r->d_foreign.p;
+  c.absw = r->d_absw.p;
   c.src = r->d_src.p;
   c.ix = r->d_ix.p;
   c.q = r->d_q.p;
@@ -358,6 +361,8 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     pp.has_cont = r->has_cont; pp.LH2O = r->LH2O;
     pp.check_radii = (r->column_has_particles && !r->part.empty()) ? 1 : 0;  // types.f90:628
     for (int s = 0; s < r->nslots; s++) pp.slots[s] = r->slots[s];
+    pp.nabs = (int)r->abs_entries.size();
+    for (int e = 0; e < pp.nabs; e++) { pp.abs_kind[e] = r->abs_entries[e].kind; pp.abs_a[e] = r->abs_entries[e].a; pp.abs_b[e] = r->abs_entries[e].b; }
     pp.col = col;
     pp.call_id = ++r->call_id;
     { KernelTimer t(r, 0); launch_prep(pp, r->stream); t.stop(); }
@@ -367,27 +372,15 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     op.nz = nz; op.nw = r->nw; op.ng = r->ng; op.nsp = r->nsp; op.np = r->np;
     op.bin_lo = r->op_lo; op.nbins = r->op_n;
     if (const char *dbg = getenv("CLIMA_HIP_DEBUG_SKIP_OP")) op.debug_skip = atoi(dbg);
-    op.nk = (int)r->k.size(); op.ncia = (int)r->cia.size(); op.nray = (int)r->ray.size();
-    op.npxs = (int)r->pxs.size(); op.npart = (int)r->part.size();
-    op.has_cont = r->has_cont; op.LH2O = r->LH2O; op.cont_nT = r->cont_nT;
-    int slot = 0;
-    for (size_t i = 0; i < r->k.size(); i++) {
-      op.k[i] = KDev{r->k[i]->d_log10k.p, r->k[i]->sp, r->k[i]->nP, r->k[i]->nT, slot, slot + 1};
-      slot += 2;
-    }
-    auto fill = [&](std::vector<XsHost *> &v, XsDev *out) {
-      for (size_t i = 0; i < v.size(); i++) {
-        out[i] = XsDev{v[i]->d_data.p, v[i]->dim, v[i]->sp1, v[i]->sp2, v[i]->nT, v[i]->dim ? slot : -1};
-        if (v[i]->dim) slot++;
-      }
-    };
-    fill(r->cia, op.cia);
-    fill(r->pxs, op.pxs);
+    op.nk = (int)r->k.size(); op.nray = (int)r->ray.size(); op.npart = (int)r->part.size();
+    for (size_t i = 0; i < r->k.size(); i++)
+      op.k[i] = KDev{r->k[i]->d_log10k.p, r->k[i]->sp, r->k[i]->nP, r->k[i]->nT, (int)(2 * i), (int)(2 * i + 1)};
     for (size_t i = 0; i < r->ray.size(); i++) op.ray[i] = XsDev{r->ray[i]->d_data.p, 0, r->ray[i]->sp1, -1, 0, -1};
-    if (r->has_cont) { op.cont_slot = slot++; op.cont_H2O = r->d_cont_H2O.p; op.cont_foreign = r->d_cont_foreign.p; }
+    op.nabs = (int)r->abs_entries.size();
+    for (int e = 0; e < op.nabs; e++) op.abs[e] = r->abs_entries[e];
     for (size_t i = 0; i < r->part.size(); i++)
-      op.part[i] = PartDev{r->part[i]->d_w0.p, r->part[i]->d_qext.p, r->part[i]->d_gt.p, r->part[i]->p_ind, r->part[i]->nrad, slot++};
-    op.wbin = r->d_wbin.p; op.wbin_e = r->d_wbin_e.p; op.wxy = r->d_wxy.p;
+      op.part[i] = PartDev{r->part[i]->d_w0.p, r->part[i]->d_qext.p, r->part[i]->d_gt.p, r->part[i]->p_ind, r->part[i]->nrad, r->part_slot[i]};
+    op.wbin = r->d_wbin.p; op.wbin_e = r->d_wbin_e.p; op.wxy = r->d_wxy.p; op.wbin_e_pad = r->d_wbin_e_pad.p;
     op.col = col;
     op.tau = r->d_tau.p; op.w0 = r->d_w0.p; op.g = r->d_g.p; op.tau_band = r->d_tau_band.p;
     {
@@ -682,23 +675,39 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
     add_slot(k->d_log10P.p, k->log10P, 0, false);
     add_slot(k->d_temp.p, k->temp, 1, false);
   }
+  r->abs_entries.clear();
   for (auto *v : {&r->cia, &r->pxs})
     for (auto *xs : *v) {
       xs->d_data.upload(xs->data);
-      if (xs->dim) { xs->d_temp.upload(xs->temp); add_slot(xs->d_temp.p, xs->temp, 1, false); }
+      AbsEntry e;
+      e.data = xs->d_data.p; e.nT = xs->dim ? xs->nT : 0; e.slot = 0;
+      e.kind = (v == &r->cia) ? ABS_CIA : ABS_COLUMN; e.a = xs->sp1; e.b = xs->sp2 < 0 ? 0 : xs->sp2;
+      if (xs->dim) { xs->d_temp.upload(xs->temp); e.slot = (int)r->slots.size(); add_slot(xs->d_temp.p, xs->temp, 1, false); }
+      r->abs_entries.push_back(e);
     }
   for (auto *xs : r->ray) xs->d_data.upload(xs->data);
-  if (r->has_cont) {
+  if (r->has_cont) {  // H2O self then foreign (types.f90:719-721)
     r->d_cont_temp.upload(r->cont_temp); r->d_cont_H2O.upload(r->cont_H2O); r->d_cont_foreign.upload(r->cont_foreign);
+    const int slot = (int)r->slots.size();
     add_slot(r->d_cont_temp.p, r->cont_temp, 1, false);
+    r->abs_entries.push_back(AbsEntry{r->d_cont_H2O.p, r->cont_nT, slot, ABS_H2O_SELF, r->LH2O, 0});
+    r->abs_entries.push_back(AbsEntry{r->d_cont_foreign.p, r->cont_nT, slot, ABS_H2O_FOREIGN, r->LH2O, 0});
   }
+  if ((int)r->abs_entries.size() > MAX_ABS) throw HipFail{"too many continuum terms for this build"};
+  r->part_slot.clear();
   for (auto *p : r->part) {
     p->d_radii.upload(p->radii); p->d_w0.upload(p->w0); p->d_qext.upload(p->qext); p->d_gt.upload(p->gt);
+    r->part_slot.push_back((int)r->slots.size());
     add_slot(p->d_radii.p, p->radii, 2 + p->p_ind, true);
   }
   r->nslots = (int)r->slots.size();
   if (r->nslots > MAX_SLOTS) throw HipFail{"too many interpolated tables for this build"};
   r->d_wbin.upload(r->wbin); r->d_wbin_e.upload(r->wbin_e); r->d_wxy.upload(r->wxy);
+  {
+    std::vector<double> pad = r->wbin_e;
+    for (int i = 0; i < 4; i++) pad.push_back(INFINITY);
+    r->d_wbin_e_pad.upload(pad);
+  }
   r->d_freq.upload(r->freq);
   r->ir.d_freq.upload(r->ir.freq); r->sol.d_freq.upload(r->sol.freq);
   // amean unit factors per solar bin (radiate.f90:174-178)
@@ -718,6 +727,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   r->d_col.zero();
   HIPCHK(hipHostMalloc((void **)&r->h_col, sizeof(double) * r->col_count));
   r->d_log10P.alloc(nz); r->d_cols.alloc((size_t)nz * r->nsp); r->d_foreign.alloc(nz);
+  r->d_absw.alloc((size_t)std::max<size_t>(1, r->abs_entries.size()) * nz);
   r->d_src.alloc(nz); r->d_ix.alloc((size_t)std::max(1, r->nslots) * nz); r->d_q.alloc((size_t)std::max(1, r->nslots) * nz);
   r->d_err.alloc(1); r->d_err.zero();
   r->d_tau.alloc((size_t)nw * ng * nz); r->d_w0.alloc((size_t)nw * ng * nz);

@@ -46,6 +46,19 @@ struct XsDev {
   int dim, sp1, sp2, nT, slot;
 };
 
+// One term of the continuum absorption taua (types.f90:696-723), in the reference's
+// summation order: CIA pairs, photolysis/absorption, H2O self and foreign continuum.
+// tau = sigma(bin, T_layer) * weight(layer); the weight is bin-independent and is formed
+// once per call by the prep kernel.
+constexpr int MAX_ABS = 2 * 16 + 2;
+enum { ABS_CIA = 0, ABS_COLUMN = 1, ABS_H2O_SELF = 2, ABS_H2O_FOREIGN = 3 };
+struct AbsEntry {
+  const double *data;  // nT == 0: xs[nw]; else log10 xs [nw][nT]
+  int nT;              // 0 for constant (0-D) cross sections
+  int slot;            // interpolation slot (any valid slot when nT == 0)
+  int kind, a, b;      // weight: CIA dens_a*dens_b*dz | cols_a | dens_a*cols_a | dens_a*foreign_col
+};
+
 struct KDev {
   const double *log10k;  // [nw][nT][nP][ng]
   int sp, nP, nT, slotP, slotT;
@@ -69,6 +82,7 @@ struct SlotDev {
 struct ColumnDev {
   const double *T, *P, *dz, *dens, *pdens, *radii;  // dens [nsp][nz], pdens/radii [np][nz]
   double *log10P, *cols, *foreign_col;
+  double *absw;    // [nabs][nz] per-layer weights of the absorption entries
   int *src;        // source layer for interpolation (j, or j-1 under pair_reuse)
   int *ix;         // [nslots][nz]
   double *q;       // [nslots][nz]
@@ -80,12 +94,14 @@ struct OpacityParams {
   int nz, nw, ng, nsp, np;
   int debug_skip;  // developer ablation mask (0 in production)
   int bin_lo, nbins;  // opacity bins handled by this launch
-  int nk, ncia, nray, npxs, npart, has_cont, LH2O, cont_slot, cont_nT;
+  int nk, nray, npart;
   KDev k[MAX_K];
-  XsDev cia[MAX_XS], ray[MAX_XS], pxs[MAX_XS];
+  XsDev ray[MAX_XS];
+  int nabs;
+  AbsEntry abs[MAX_ABS];
   PartDev part[MAX_PART];
-  const double *cont_H2O, *cont_foreign;  // [nw][nT]
   const double *wbin, *wbin_e, *wxy;      // Ksettings (types.f90:84-94)
+  const double *wbin_e_pad;               // wbin_e followed by +inf sentinels (edge stream of the rebin)
   ColumnDev col;
   double *tau, *w0, *g, *tau_band;        // opr
 };
@@ -94,6 +110,8 @@ struct PrepParams {
   int nz, nsp, np, nslots, has_cont, LH2O, check_radii;
   int call_id;  // stamped into err_flag by a failing call (monotonic, so the flag never needs a reset)
   SlotDev slots[MAX_SLOTS];
+  int nabs;
+  int abs_kind[MAX_ABS], abs_a[MAX_ABS], abs_b[MAX_ABS];
   ColumnDev col;
 };
 

@@ -7,6 +7,8 @@ from clima_amd.radtran import Radtran
 tb = S.modern_earth_tables()
 col = S.modern_earth_column(200)
 r = Radtran(tb, 200, 8, 0.15)
+import sys as _s
+if len(_s.argv) > 1: r.set_bin_shard(0, int(_s.argv[1]))
 r.upload_column(*col.args())
 names = ["prep", "opacity", "twostream", "integrate"]
 for label, env in (("full", {}), ("ts: no thomas", {"CLIMA_HIP_DEBUG_SKIP_TS": "1"}), ("ts: 1 zenith", {"CLIMA_HIP_DEBUG_SKIP_TS": "2"}),
