@@ -42,13 +42,40 @@ __device__ __forceinline__ double rcp_nr(double x) {
   return r;
 }
 
+// fast_exp(x) in ~20 f64 instructions (the ocml exp is ~2x that): k = rint(x*log2e),
+// r = x - k*ln2 (two-term Cody-Waite), degree-13 Taylor polynomial in r (|r| <= 0.35,
+// truncation 5e-18), scaled by 2^k.  Error <= 1 ulp over the arguments of this path;
+// underflows to 0 like exp().  tests/test_gpu_parity.py::test_device_exp checks it.
+__device__ __forceinline__ double fast_exp(double x) {
+  const double k = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                 // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);     // 1/12!
+  p = __builtin_fma(p, r, 2.505210838544172e-08);    // 1/11!
+  p = __builtin_fma(p, r, 2.755731922398589e-07);    // 1/10!
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);   // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873e-05);     // 1/8!
+  p = __builtin_fma(p, r, 1.984126984126984e-04);    // 1/7!
+  p = __builtin_fma(p, r, 1.388888888888889e-03);    // 1/6!
+  p = __builtin_fma(p, r, 8.333333333333333e-03);    // 1/5!
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);   // 1/4!
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);   // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  int ki = (int)k;
+  ki = ki < -2000 ? -2000 : ki;                      // fast_exp(-inf) -> 0 without UB in the cast
+  return __builtin_ldexp(p, x > 709.0 ? 2000 : ki);
+}
+
 // ten2power, src/clima_eqns.f90:75-80
-__device__ __forceinline__ double ten2power(double y) { return exp(y * LN10); }
+__device__ __forceinline__ double ten2power(double y) { return fast_exp(y * LN10); }
 
 // planck_fcn, src/clima_eqns.f90:64-73
 __device__ __forceinline__ double planck_fcn(double nu, double T) {
   return 1.0e3 * ((2.0 * PLANK * (nu * nu * nu)) / (C_LIGHT * C_LIGHT)) *
-         ((1.0) / (exp((PLANK * nu) / (K_BOLTZ_SI * T)) - 1.0));
+         ((1.0) / (fast_exp((PLANK * nu) / (K_BOLTZ_SI * T)) - 1.0));
 }
 
 // futils is_close (fortran-stdlib form): |a-b| <= tol*max(|a|,|b|)
@@ -164,7 +191,7 @@ constexpr int OP_THREADS = 256;
 // in the 6 low mantissa bits: that orders ties exactly like the stable rank on
 // (value,index) whenever two values differ above 2^-46 relative, and it is how the sorted
 // stream finds its weight wxy(idx).  The value used downstream is the key with those bits
-// cleared (relative perturbation <= 2^-46 = 1.4e-14, below the 3e-14 that the exp() argument
+// cleared (relative perturbation <= 2^-46 = 1.4e-14, below the 3e-14 that the fast_exp() argument
 // rounding of the k-table interpolation already carries).  When y is ascending (the normal
 // case for k-distributions) the 8 runs of 8 keys are pre-sorted and only the merge tail of
 // the network runs.
@@ -413,7 +440,7 @@ bool launch_opacity(const OpacityParams &p, hipStream_t s) {
 //
 // LDS image: 6 arrays [nz][nc] f64, recycled through the phases
 //     G  : cap_gamma          -> c' row 2i    -> beta  row 2i    -> staging fup
-//     X  : exp(-lambda tau)   -> c' row 2i+1  -> beta  row 2i+1  -> staging fdn
+//     X  : fast_exp(-lambda tau)   -> c' row 2i+1  -> beta  row 2i+1  -> staging fdn
 //     E0 : tau'/tauc, cp0     -> E  row 2i    -> d' -> alpha row 2i -> staging amean
 //     E1 : cm0                -> E  row 2i+1  -> d' -> alpha row 2i+1
 //     U  :                       l  row 2i    -> gamma row 2i
@@ -614,7 +641,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_twostream(TwoStreamParams p) {
         const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
         ktau[k] = tau; kw0[k] = w0; kgt[k] = gt; klam[k] = lam;
         kG[k] = gam2 / (gam1 + lam);
-        kx[k] = exp(-lam * tau);
+        kx[k] = fast_exp(-lam * tau);
         s.E0[pr] = tau;
       }
     }
@@ -663,8 +690,8 @@ __global__ __launch_bounds__(MAXT, MINW) void k_twostream(TwoStreamParams p) {
           const double gam4 = 1.0 - gam3;
           const double facp = kw0[k] * ((gam1 - iu) * gam3 + gam4 * gam2);
           const double facm = kw0[k] * ((gam1 + iu) * gam4 + gam2 * gam3);
-          const double et0 = exp(-tauc * iu);
-          const double etb = et0 * exp(-ktau[k] * iu);
+          const double et0 = fast_exp(-tauc * iu);
+          const double etb = et0 * fast_exp(-ktau[k] * iu);
           const double rden = wz * rcp_nr(lam2 - iu * iu);  // w_z / denom (:80)
           const double fp = facp * rden, fm = facm * rden;
           CP0 = __builtin_fma(et0, fp, CP0);
@@ -706,7 +733,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_twostream(TwoStreamParams p) {
         const double gam2 = w0 * (1.0 - gt);
         const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
         const double G = gam2 / (gam1 + lam);
-        const double x = exp(-lam * tau);
+        const double x = fast_exp(-lam * tau);
         double b0n, b1n;  // :216-227
         if (tau <= p.ir_tau_min) {
           b0n = 0.5 * (s.Bp[i] + s.Bp[i + 1]);
@@ -881,6 +908,8 @@ __global__ __launch_bounds__(256) void k_zero(ZeroParams z) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0;
 }
 
+static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s);
+
 // LDS bytes for nc columns per block
 static size_t ts_lds_bytes(int nz, int nc, int S) {
   return sizeof(double) * ((size_t)6 * nz * nc + (nz + 1) + 3 * nc + (size_t)((nz + 7) / 8) * nc + (size_t)6 * S * nc + (size_t)(nz + 2) / 2 + 1);
@@ -920,21 +949,7 @@ bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
   const int grid = p.n_sol + p.n_ir;
   if (grid <= 0) return true;
   const dim3 g(grid, p.ng / nc);
-  if (g.y > 1) {  // partial sums over g-point groups accumulate into zeroed outputs: one launch
-    const size_t nl = (size_t)p.nz + 1;
-    ZeroParams z;
-    z.n = 0;
-    if (p.n_ir > 0) {
-      z.ptr[z.n] = p.ir_fup_a + (size_t)p.ir_lo * nl; z.count[z.n++] = nl * p.n_ir;
-      z.ptr[z.n] = p.ir_fdn_a + (size_t)p.ir_lo * nl; z.count[z.n++] = nl * p.n_ir;
-    }
-    if (p.n_sol > 0) {
-      z.ptr[z.n] = p.sol_fup_a + (size_t)p.sol_lo * nl; z.count[z.n++] = nl * p.n_sol;
-      z.ptr[z.n] = p.sol_fdn_a + (size_t)p.sol_lo * nl; z.count[z.n++] = nl * p.n_sol;
-      z.ptr[z.n] = p.sol_amean + (size_t)p.sol_lo * nl; z.count[z.n++] = nl * p.n_sol;
-    }
-    if (z.n > 0) hipLaunchKernelGGL(k_zero, dim3(128, z.n), dim3(256), 0, s, z);
-  }
+  if (g.y > 1) ts_zero_outputs(p, s);
   if (threads <= 512) {
     static bool attr512 = false;
     if (!attr512) { (void)hipFuncSetAttribute((const void *)k_twostream<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr512 = true; }
@@ -943,6 +958,406 @@ bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
     static bool attr1024 = false;
     if (!attr1024) { (void)hipFuncSetAttribute((const void *)k_twostream<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1024 = true; }
     hipLaunchKernelGGL((k_twostream<1024, 4>), g, dim3(threads), lds, s, p);
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------
+// k_twostream_w: wave-per-column form of the two-stream solve (no block barriers, no
+// serial phase).  One wave = one (channel, bin, g-point) column; lane q owns the chunk of
+// consecutive layers [q*nz/64, (q+1)*nz/64) (<= LMAX layers) entirely in registers.  The
+// chunk is solved as a two-stream problem of its own with flux boundary conditions (same
+// construction as dd_solve above), which turns it into an affine map
+//     (Din, Uin) -> (Dout, Uout) = (dS + dD*Din + dU*Uin,  uS + uD*Din + uU*Uin).
+// The 64 chunks of the column are joined by two wave-level scans over shuffles:
+//   * bottom-up: the reflectance/source (rho, sigma) seen from above each interface,
+//       Uin_{q-1} = rho_{q-1}*Din_q + sigma_{q-1},
+//     is a Moebius recursion in rho; written projectively, (n_rho, n_sigma, den) <- M_q * (...)
+//     with M_q = [[uU*dD-uD*dU, 0, uD], [uU*dS-uS*dU, uU, uS], [-dU, 0, 1]], it becomes a
+//     suffix product of 3x3 matrices (7 structural non-zeros), i.e. a 6-step Kogge-Stone scan;
+//   * top-down: Din_{q+1} = alpha_q + beta_q*Din_q, an affine prefix scan.
+// A block is 4 waves = 4 g-point columns of one bin; their weighted level fluxes meet in LDS
+// once at the end.
+// ------------------------------------------------------------------------------------
+struct M7 {
+  double m00, m02, m10, m11, m12, m20, m22;
+};
+__device__ __forceinline__ M7 m7_mul(const M7 &l, const M7 &r) {
+  M7 p;
+  p.m00 = l.m00 * r.m00 + l.m02 * r.m20;
+  p.m02 = l.m00 * r.m02 + l.m02 * r.m22;
+  p.m10 = l.m10 * r.m00 + l.m11 * r.m10 + l.m12 * r.m20;
+  p.m11 = l.m11 * r.m11;
+  p.m12 = l.m10 * r.m02 + l.m11 * r.m12 + l.m12 * r.m22;
+  p.m20 = l.m20 * r.m00 + l.m22 * r.m20;
+  p.m22 = l.m20 * r.m02 + l.m22 * r.m22;
+  return p;
+}
+__device__ __forceinline__ M7 m7_shfl_down(const M7 &a, int d) {
+  M7 r;
+  r.m00 = __shfl_down(a.m00, d); r.m02 = __shfl_down(a.m02, d); r.m10 = __shfl_down(a.m10, d);
+  r.m11 = __shfl_down(a.m11, d); r.m12 = __shfl_down(a.m12, d); r.m20 = __shfl_down(a.m20, d);
+  r.m22 = __shfl_down(a.m22, d);
+  return r;
+}
+
+constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
+
+template <int LMAX, bool SOLAR>
+__global__ __launch_bounds__(64 * TSW_COLS) void k_twostream_w(TwoStreamParams p) {
+  extern __shared__ __align__(16) double lds[];  // [3][TSW_COLS][nz+1] weighted level values
+  const int nz = p.nz, ng = p.ng, nl = nz + 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr bool solar = SOLAR;  // one launch per channel: blockIdx.x is the channel-local bin
+  const int ll = (solar ? p.sol_lo : p.ir_lo) + (int)blockIdx.x;
+  const int l = (solar ? p.sol_start : p.ir_start) + ll;  // opacity bin (radiate.f90:57)
+  const int c_raw = blockIdx.y * TSW_COLS + wave;
+  const bool col_on = c_raw < ng;
+  const int c = col_on ? c_raw : ng - 1;
+  const double wcol = col_on ? p.wbin[c] : 0.0;  // g-point weight (radiate.f90:122-126)
+  const double *tauL = p.tau + ((size_t)l * ng + c) * nz;
+  const double *w0L = p.w0 + ((size_t)l * ng + c) * nz;
+  const double *gL = p.g + (size_t)l * nz;
+  const int a = (lane * nz) >> 6, b = ((lane + 1) * nz) >> 6, len = b - a;  // layers [a,b), TOA-first
+
+  // kept per layer for the flux evaluation, and the rows of the chunk's tridiagonal system
+  double G[LMAX], X[LMAX], cpb[LMAX], cmb[LMAX], dir[LMAX], diru[LMAX];
+  double rc[2 * LMAX], rd[2 * LMAX], rl[2 * LMAX];
+  double Rsfc, lvl0_dn = 0.0, lvl0_am = 0.0, cp0_top = 0.0;
+  const double inv_u1 = solar ? 1.7320508075688772 : 0.0;  // 1/u1, u1 = 1/sqrt(3) (solar only)
+  const double sqrt3 = 1.7320508075688772;
+
+  // ---- solar: optical depth above the chunk (tauc, twostream.f90:64-67) = exclusive wave
+  //      scan of the chunk totals of the delta-scaled optical depths
+  double tcum = 0.0;
+  if constexpr (solar) {
+    double tot = 0.0;
+#pragma unroll
+    for (int t = 0; t < LMAX; t++)
+      if (t < len) {
+        const double tau_in = tauL[a + t], w0_in = w0L[a + t], gt_in = gL[a + t];
+        tot = tot + tau_in * (1.0 - w0_in * gt_in * gt_in);
+      }
+    double incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double nb = __shfl_up(incl, d);
+      if (lane >= d) incl = incl + nb;
+    }
+    tcum = __shfl_up(incl, 1);
+    if (lane == 0) tcum = 0.0;
+    double wsum = 0.0, dir0 = 0.0;
+    for (int z = 0; z < p.nzen; z++) { wsum = wsum + p.zen_w[z]; dir0 = dir0 + p.zen_w[z] * p.zen_u[z]; }
+    lvl0_dn = dir0;   // direct(1) = u0 (:73)
+    lvl0_am = wsum;   // direct(1)/u0 = 1
+    Rsfc = p.albedo[ll];
+  } else {
+    Rsfc = p.has_hard_surface ? 1.0 - p.emissivity[ll] : 0.0;  // :186-190
+  }
+  const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64 (IR)
+
+  // ---- layer by layer: optical coefficients and source terms of layer t, then the rows of
+  //      the chunk's system that become complete with it, eliminated downward at once
+  //      (y_r + c' y_{r+1} + l*Din = d').  Row 2t-1 couples layers t-1,t (Fortran even rows,
+  //      :106-112), row 2t likewise (odd rows, :97-103); row 0 and the chunk's last row are
+  //      the flux boundary rows (TOA :93-96 / surface :113-117 at the column ends).
+  {
+    double cp = 0.0, dp = 0.0, lp = -1.0;
+    E4 u = make_e(0.0, 0.0);
+    double cpb_u = 0.0, cmb_u = 0.0;
+    double bpl_top = 0.0;  // IR: Planck at the top level of the current layer
+    constexpr int NZMAX = 0;  // zenith angles whose direct-beam transmission is carried layer to layer (0: recompute)
+    double etc[NZMAX + 1];
+#pragma unroll
+    for (int z = 0; z < NZMAX; z++) etc[z] = 1.0;
+    if constexpr (!solar)
+      if (len > 0) bpl_top = planck_fcn(avg_freq, a == nz ? *p.T_surface : p.T[nz - 1 - a]);
+#pragma unroll
+    for (int t = 0; t < LMAX; t++) {
+      G[t] = X[t] = cpb[t] = cmb[t] = dir[t] = diru[t] = 0.0;
+      rc[2 * t] = rc[2 * t + 1] = rd[2 * t] = rd[2 * t + 1] = rl[2 * t] = rl[2 * t + 1] = 0.0;
+      if (t < len) {
+        const int i = a + t;
+        const double tau_in = tauL[i], w0_in = w0L[i], gt_in = gL[i];
+        double cp0, cm0, Ssfc = 0.0;
+        if constexpr (solar) {
+          // delta-Eddington (:38-40), quadrature coefficients (:43-44), lambda, Gamma (:50-51)
+          const double taup = tau_in * (1.0 - w0_in * gt_in * gt_in);
+          const double w0p = w0_in * (1.0 - gt_in * gt_in) / (1.0 - w0_in * gt_in * gt_in);
+          const double gtp = gt_in / (1.0 + gt_in);
+          const double gam1 = sqrt3 * (2.0 - w0p * (1 + gtp)) / 2.0;
+          const double gam2 = sqrt3 * w0p * (1.0 - gtp) / 2.0;
+          const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
+          G[t] = gam2 / (gam1 + lam);
+          X[t] = fast_exp(-lam * taup);  // :56
+          const double tauc = tcum;
+          tcum = tcum + taup;
+          // C+/C- and direct beam (:73-87) summed over the zenith angles with their weights
+          // (the matrix does not depend on u0: sum_z w_z*solve(E_z) == solve(sum_z w_z*E_z))
+          const double lam2 = lam * lam;
+          double CP0 = 0.0, CPB = 0.0, CM0 = 0.0, CMB = 0.0, DIR = 0.0, DIRU = 0.0;
+#pragma unroll
+          for (int z = 0; z < NZMAX; z++) {
+            if (z < p.nzen) {
+              const double u0 = p.zen_u[z], wz = p.zen_w[z], iu = p.zen_iu[z];
+              const double gam3 = (1.0 - sqrt3 * gtp * u0) / 2.0;
+              const double gam4 = 1.0 - gam3;
+              const double facp = w0p * ((gam1 - iu) * gam3 + gam4 * gam2);
+              const double facm = w0p * ((gam1 + iu) * gam4 + gam2 * gam3);
+              // exp(-tauc/u0) at the top of the layer (:78): computed for the chunk's first
+              // layer, afterwards carried from the layer above (etb there is the same quantity)
+              const double et0 = (t == 0) ? fast_exp(-tauc * iu) : etc[z];
+              const double etb = et0 * fast_exp(-taup * iu);  // :79
+              etc[z] = etb;
+              const double rden = wz * rcp_nr(lam2 - iu * iu);  // w_z / denom (:80)
+              const double fp = facp * rden, fm = facm * rden;
+              CP0 = __builtin_fma(et0, fp, CP0);
+              CPB = __builtin_fma(etb, fp, CPB);
+              CM0 = __builtin_fma(et0, fm, CM0);
+              CMB = __builtin_fma(etb, fm, CMB);
+              DIR = __builtin_fma(wz * u0, etb, DIR);   // direct(i+1) = u0*etb (:82)
+              DIRU = __builtin_fma(wz, etb, DIRU);      // direct(i+1)/u0
+            }
+          }
+          for (int z = NZMAX; z < p.nzen; z++) {  // more zenith angles than the carried set: recompute
+            const double u0 = p.zen_u[z], wz = p.zen_w[z], iu = p.zen_iu[z];
+            const double gam3 = (1.0 - sqrt3 * gtp * u0) / 2.0;
+            const double gam4 = 1.0 - gam3;
+            const double facp = w0p * ((gam1 - iu) * gam3 + gam4 * gam2);
+            const double facm = w0p * ((gam1 + iu) * gam4 + gam2 * gam3);
+            const double et0 = fast_exp(-tauc * iu);
+            const double etb = et0 * fast_exp(-taup * iu);
+            const double rden = wz * rcp_nr(lam2 - iu * iu);
+            const double fp = facp * rden, fm = facm * rden;
+            CP0 = __builtin_fma(et0, fp, CP0);
+            CPB = __builtin_fma(etb, fp, CPB);
+            CM0 = __builtin_fma(et0, fm, CM0);
+            CMB = __builtin_fma(etb, fm, CMB);
+            DIR = __builtin_fma(wz * u0, etb, DIR);
+            DIRU = __builtin_fma(wz, etb, DIRU);
+          }
+          cp0 = CP0; cm0 = CM0; cpb[t] = CPB; cmb[t] = CMB; dir[t] = DIR; diru[t] = DIRU;
+          Ssfc = Rsfc * DIR;  // :89 (used by the surface row only)
+        } else {
+          const double gam1 = 2.0 - w0_in * (1.0 + gt_in);  // :195-201
+          const double gam2 = w0_in * (1.0 - gt_in);
+          const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
+          G[t] = gam2 / (gam1 + lam);
+          X[t] = fast_exp(-lam * tau_in);
+          const double bpl_bot = planck_fcn(avg_freq, i + 1 == nz ? *p.T_surface : p.T[nz - 2 - i]);  // radiate.f90:65-69
+          double b0n, b1n;  // :216-227
+          if (tau_in <= p.ir_tau_min) {
+            b0n = 0.5 * (bpl_top + bpl_bot);
+            b1n = 0.0;
+          } else {
+            b0n = bpl_top;
+            b1n = (bpl_bot - b0n) / tau_in;
+          }
+          const double norm = 2.0 * PI * 0.5;
+          const double r = 1.0 / (gam1 + gam2);
+          cp0 = norm * (b0n + b1n * (r));  // :229-232
+          cpb[t] = norm * (b0n + b1n * (tau_in + r));
+          cm0 = norm * (b0n + b1n * (-r));
+          cmb[t] = norm * (b0n + b1n * (tau_in - r));
+          if (p.has_hard_surface) {  // :236-247 (used by the surface row only)
+            Ssfc = p.emissivity[ll] * PI * bpl_bot;
+          } else {
+            const double b1_bot = (tau_in <= p.ir_tau_min) ? 0.0 : (bpl_bot - bpl_top) / tau_in;
+            Ssfc = PI * (bpl_bot + 0.5 * b1_bot);
+          }
+          bpl_top = bpl_bot;
+        }
+        const E4 v = make_e(G[t], X[t]);
+        if (t == 0) {
+          cp0_top = cp0;
+          // row 0: TOA row (:93-96) or the flux condition "-Din + e1 y1 - e2 y2 = -cm0"
+          const double A = (a == 0) ? 0.0 : -1.0;
+          const double r = rcp_nr(v.e1 - A * cp);
+          cp = (-v.e2) * r; dp = ((0.0 - cm0) - A * dp) * r; lp = (-A * lp) * r;
+          rc[0] = cp; rd[0] = dp; rl[0] = lp;
+        } else {
+          // row 2t-1 (layers t-1, t)
+          double A = v.e2 * u.e1 - u.e3 * v.e4, B = u.e2 * v.e2 - u.e4 * v.e4, D = v.e1 * v.e4 - v.e2 * v.e3;
+          double E = v.e2 * (cp0 - cpb_u) - v.e4 * (cm0 - cmb_u);
+          double r = rcp_nr(B - A * cp);
+          double cn = D * r, dn = (E - A * dp) * r, ln = (-A * lp) * r;
+          rc[2 * t - 1] = cn; rd[2 * t - 1] = dn; rl[2 * t - 1] = ln;
+          // row 2t
+          A = u.e2 * u.e3 - u.e4 * u.e1; B = u.e1 * v.e1 - u.e3 * v.e3; D = u.e3 * v.e4 - u.e1 * v.e2;
+          E = u.e3 * (cp0 - cpb_u) + u.e1 * (cmb_u - cm0);
+          r = rcp_nr(B - A * cn);
+          cp = D * r; dp = (E - A * dn) * r; lp = (-A * ln) * r;
+          rc[2 * t] = cp; rd[2 * t] = dp; rl[2 * t] = lp;
+        }
+        if (t == len - 1) {
+          // last row of the chunk: surface row (:113-117) or "e1 y1 + e2 y2 - Uin = -cpb"
+          double A, B, D, E;
+          if (b == nz) { A = v.e1 - Rsfc * v.e3; B = v.e2 - Rsfc * v.e4; D = 0.0; E = Ssfc - cpb[t] + Rsfc * cmb[t]; }
+          else { A = v.e1; B = v.e2; D = -1.0; E = 0.0 - cpb[t]; }
+          const double r = rcp_nr(B - A * cp);
+          const double cn = D * r, dn = (E - A * dp) * r, ln = (-A * lp) * r;
+          rc[2 * t + 1] = cn; rd[2 * t + 1] = dn; rl[2 * t + 1] = ln;
+        }
+        u = v; cpb_u = cpb[t]; cmb_u = cmb[t];
+      }
+    }
+  }
+  // ---- upward: y_r = alpha_r + beta_r*Uin + gamma_r*Din   (alpha -> rd, beta -> rc, gamma -> rl)
+  double aB0 = 0, bB0 = 0, gB0 = 0, aB1 = 0, bB1 = 0, gB1 = 0;
+  {
+    double al = 0.0, be = 1.0, ga = 0.0;
+#pragma unroll
+    for (int r = 2 * LMAX - 1; r >= 0; r--) {
+      if (r < 2 * len) {
+        const double cc = rc[r], dd = rd[r], lc = rl[r];
+        al = dd - cc * al; be = -cc * be; ga = -lc - cc * ga;
+        rd[r] = al; rc[r] = be; rl[r] = ga;
+        if (r == 2 * len - 1) { aB1 = al; bB1 = be; gB1 = ga; }
+        if (r == 2 * len - 2) { aB0 = al; bB0 = be; gB0 = ga; }
+      }
+    }
+  }
+  // ---- the chunk as an affine map of (Din, Uin); empty chunks are the identity
+  double uS = 0.0, uD = 0.0, uU = 1.0, dS = 0.0, dD = 1.0, dU = 0.0;
+  if (len > 0) {
+    const E4 ea = make_e(G[0], X[0]);
+    double Gb = G[0], Xb = X[0], cmbb = cmb[0];
+#pragma unroll
+    for (int t = 1; t < LMAX; t++)
+      if (t == len - 1) { Gb = G[t]; Xb = X[t]; cmbb = cmb[t]; }
+    const E4 eb = make_e(Gb, Xb);
+    // up-flux leaving through the chunk's top (fup(1) form, :143), down-flux through its bottom (:147)
+    uS = rd[0] * ea.e3 - rd[1] * ea.e4 + cp0_top; uD = rl[0] * ea.e3 - rl[1] * ea.e4; uU = rc[0] * ea.e3 - rc[1] * ea.e4;
+    dS = aB0 * eb.e3 + aB1 * eb.e4 + cmbb; dD = gB0 * eb.e3 + gB1 * eb.e4; dU = bB0 * eb.e3 + bB1 * eb.e4;
+  }
+  // ---- bottom-up suffix scan of the projective reflectance recursion
+  M7 P;
+  P.m00 = uU * dD - uD * dU; P.m02 = uD; P.m10 = uU * dS - uS * dU; P.m11 = uU; P.m12 = uS; P.m20 = -dU; P.m22 = 1.0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const M7 R = m7_shfl_down(P, d);
+    if (lane + d < 64) P = m7_mul(P, R);
+  }
+  // P applied to (0,0,1): state above chunk `lane`; the state below it lives one lane down
+  const double rinv = rcp_nr(P.m22);
+  const double rho_above = P.m02 * rinv, sig_above = P.m12 * rinv;
+  double rho = __shfl_down(rho_above, 1), sig = __shfl_down(sig_above, 1);
+  if (lane == 63) { rho = 0.0; sig = 0.0; }
+  // ---- top-down affine scan: Din_{q+1} = alpha_q + beta_q*Din_q
+  const double mm = rcp_nr(1.0 - rho * dU);
+  double sa = dS + dU * mm * (rho * dS + sig);
+  double sb = dD * (1.0 + dU * mm * rho);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double pa = __shfl_up(sa, d), pb = __shfl_up(sb, d);
+    if (lane >= d) { sa = sa + sb * pa; sb = sb * pb; }
+  }
+  double Din = __shfl_up(sa, 1);
+  if (lane == 0) Din = 0.0;
+  const double Uin = mm * (rho * dS + sig + rho * dD * Din);
+
+  // ---- level fluxes (:143-148, :288-293), mean intensity (:135-140), g-point weight
+  double *sFu = lds + (size_t)(0 * TSW_COLS + wave) * nl;
+  double *sFd = lds + (size_t)(1 * TSW_COLS + wave) * nl;
+  double *sAm = lds + (size_t)(2 * TSW_COLS + wave) * nl;
+#pragma unroll
+  for (int t = 0; t < LMAX; t++) {
+    if (t < len) {
+      const int i = a + t;
+      const E4 e = make_e(G[t], X[t]);
+      const double y1 = rd[2 * t] + rc[2 * t] * Uin + rl[2 * t] * Din;
+      const double y2 = rd[2 * t + 1] + rc[2 * t + 1] * Uin + rl[2 * t + 1] * Din;
+      sFu[i + 1] = wcol * (y1 * e.e1 + y2 * e.e2 + cpb[t]);
+      sFd[i + 1] = wcol * ((y1 * e.e3 + y2 * e.e4 + cmb[t]) + dir[t]);
+      sAm[i + 1] = wcol * (inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + cpb[t] + cmb[t]) + diru[t]);
+      if (i == 0) {
+        const double top = (y1 * e.e3 - y2 * e.e4) + cp0_top;
+        sFu[0] = wcol * top;
+        sFd[0] = wcol * lvl0_dn;
+        sAm[0] = wcol * (inv_u1 * top + lvl0_am);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- sum over the block's g-points, unit factors (radiate.f90:167-180), reversal (:140-154)
+  const bool split = gridDim.y > 1;
+  double scale = 1.0;
+  if (solar) scale = p.photons_sol[ll] * p.photon_scale_factor;  // clima_radtran.f90:302
+  for (int n = threadIdx.x; n < nl; n += blockDim.x) {
+    double fu = 0.0, fd = 0.0, am = 0.0;
+#pragma unroll
+    for (int w = 0; w < TSW_COLS; w++) {
+      fu = fu + lds[(size_t)(0 * TSW_COLS + w) * nl + n];
+      fd = fd + lds[(size_t)(1 * TSW_COLS + w) * nl + n];
+      am = am + lds[(size_t)(2 * TSW_COLS + w) * nl + n];
+    }
+    const size_t o = (size_t)ll * nl + (nz - n);
+    if (solar) {
+      fu = fu * scale * p.diurnal_fac;
+      fd = fd * scale * p.diurnal_fac;
+      am = am * scale * p.diurnal_fac;
+      am = am * p.am_f1[ll];
+      am = am * p.am_f2[ll] * p.am_dw[ll];
+      if (split) { atomicAdd(&p.sol_fup_a[o], fu); atomicAdd(&p.sol_fdn_a[o], fd); atomicAdd(&p.sol_amean[o], am); }
+      else { p.sol_fup_a[o] = fu; p.sol_fdn_a[o] = fd; p.sol_amean[o] = am; }
+    } else {
+      if (split) { atomicAdd(&p.ir_fup_a[o], fu); atomicAdd(&p.ir_fdn_a[o], fd); }
+      else { p.ir_fup_a[o] = fu; p.ir_fdn_a[o] = fd; }
+    }
+  }
+  if (blockIdx.y == 0) {
+    double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
+    for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = p.tau_band[(size_t)l * nz + (nz - 1 - i)];
+  }
+}
+
+static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
+  // partial sums over g-point groups accumulate into zeroed outputs: one launch
+  const size_t nl = (size_t)p.nz + 1;
+  ZeroParams z;
+  z.n = 0;
+  if (p.n_ir > 0) {
+    z.ptr[z.n] = p.ir_fup_a + (size_t)p.ir_lo * nl; z.count[z.n++] = nl * p.n_ir;
+    z.ptr[z.n] = p.ir_fdn_a + (size_t)p.ir_lo * nl; z.count[z.n++] = nl * p.n_ir;
+  }
+  if (p.n_sol > 0) {
+    z.ptr[z.n] = p.sol_fup_a + (size_t)p.sol_lo * nl; z.count[z.n++] = nl * p.n_sol;
+    z.ptr[z.n] = p.sol_fdn_a + (size_t)p.sol_lo * nl; z.count[z.n++] = nl * p.n_sol;
+    z.ptr[z.n] = p.sol_amean + (size_t)p.sol_lo * nl; z.count[z.n++] = nl * p.n_sol;
+  }
+  if (z.n > 0) hipLaunchKernelGGL(k_zero, dim3(128, z.n), dim3(256), 0, s, z);
+}
+
+// wave-per-column launcher; false when nz needs more than 8 layers per lane
+bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
+  const int lmax = (p.nz + 63) / 64;
+  if (lmax > 8) return false;
+  const int groups = (p.ng + TSW_COLS - 1) / TSW_COLS;
+  if (groups > 2) return false;  // keep at most two partial sums per output (order-independent)
+  const size_t lds = sizeof(double) * 3 * TSW_COLS * ((size_t)p.nz + 1);
+  if (lds_bytes) *lds_bytes = lds;
+  if (lds > 160 * 1024) return false;
+  if (p.n_sol + p.n_ir <= 0) return true;
+  if (groups > 1) ts_zero_outputs(p, s);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)k_twostream_w<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_twostream_w<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_twostream_w<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_twostream_w<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const dim3 blk(64 * TSW_COLS);
+  // the heavier solar channel first; the two launches are independent of each other
+  if (p.n_sol > 0) {
+    const dim3 g(p.n_sol, groups);
+    if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4, true>), g, blk, lds, s, p);
+    else hipLaunchKernelGGL((k_twostream_w<8, true>), g, blk, lds, s, p);
+  }
+  if (p.n_ir > 0) {
+    const dim3 g(p.n_ir, groups);
+    if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4, false>), g, blk, lds, s, p);
+    else hipLaunchKernelGGL((k_twostream_w<8, false>), g, blk, lds, s, p);
   }
   return true;
 }
@@ -1012,6 +1427,14 @@ void launch_f_total(int nz, const double *flux_n, double *f_total, hipStream_t s
 __global__ void k_scale(double *a, size_t n, double f) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = a[i] * f;
 }
+__global__ void k_test_exp(const double *x, double *y, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = fast_exp(x[i]);
+}
+void launch_test_exp(const double *x, double *y, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_test_exp, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
+}
+
 void launch_scale(double *a, size_t n, double f, hipStream_t s) {
   if (n == 0) return;
   int grid = (int)((n + 255) / 256);

@@ -413,8 +413,13 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   ts.sol_tau_band = r->wrk_sol.tau_band.p;
   {
     KernelTimer t(r, 2);
-    if (!launch_twostream(ts, r->stream, &r->ts_lds))
-      throw HipFail{"nz*ngauss = " + std::to_string(nz * r->ng) + " exceeds what the two-stream kernel can stage in 160 KiB of LDS"};
+    // default: wave-per-column kernel; CLIMA_HIP_TS_MODE=block selects the workgroup-per-bin form
+    const char *mode = getenv("CLIMA_HIP_TS_MODE");
+    bool ok = false;
+    if (!(mode && std::strcmp(mode, "block") == 0)) ok = launch_twostream_w(ts, r->stream, &r->ts_lds);
+    if (!ok) ok = launch_twostream(ts, r->stream, &r->ts_lds);
+    if (!ok)
+      throw HipFail{"nz*ngauss = " + std::to_string(nz * r->ng) + " exceeds what the two-stream kernels can stage"};
     t.stop();
   }
 
@@ -971,6 +976,17 @@ void radtran_opr_get(void *ptr, double *tau, double *w0, double *g, double *tau_
   if (w0) HIPCHK(hipMemcpy(w0, r->d_w0.p, r->d_w0.n * sizeof(double), hipMemcpyDeviceToHost));
   if (g) HIPCHK(hipMemcpy(g, r->d_g.p, r->d_g.n * sizeof(double), hipMemcpyDeviceToHost));
   if (tau_band) HIPCHK(hipMemcpy(tau_band, r->d_tau_band.p, r->d_tau_band.n * sizeof(double), hipMemcpyDeviceToHost));
+  CATCH(err)
+}
+
+void clima_test_device_exp(const int *n, const double *x, double *y, char *err) {
+  clear_err(err);
+  TRY
+  DevBuf<double> dx, dy;
+  dx.alloc(*n); dy.alloc(*n);
+  HIPCHK(hipMemcpy(dx.p, x, sizeof(double) * *n, hipMemcpyHostToDevice));
+  launch_test_exp(dx.p, dy.p, *n, nullptr);
+  HIPCHK(hipMemcpy(y, dy.p, sizeof(double) * *n, hipMemcpyDeviceToHost));
   CATCH(err)
 }
 

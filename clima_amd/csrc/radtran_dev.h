@@ -160,9 +160,11 @@ void launch_prep(const PrepParams &p, hipStream_t s);
 // returns false when ng is unsupported by the compiled kernels
 bool launch_opacity(const OpacityParams &p, hipStream_t s);
 bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
+bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
 int integrate_chunks(int nbins);
 void launch_f_total(int nz, const double *flux_n, double *f_total, hipStream_t s);
 void launch_scale(double *a, size_t n, double f, hipStream_t s);
+void launch_test_exp(const double *x, double *y, int n, hipStream_t s);
 
 }  // namespace clima

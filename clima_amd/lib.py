@@ -46,6 +46,7 @@ SIGNATURES = {
     "radtran_profile_reset": [_vp],
     "radtran_algorithmic_bytes": [_vp, _dp, _dp, _dp, _dp, _err],
     "radtran_opr_get": [_vp, _dp, _dp, _dp, _dp, _err],
+    "clima_test_device_exp": [_ip, _dp, _dp, _err],
     "radtran_set_bolometric_flux_wrapper": [_vp, _dp],
     "radtran_bolometric_flux_wrapper": [_vp, _dp],
     "radtran_skin_temperature_wrapper": [_vp, _dp, _dp],

@@ -136,6 +136,9 @@ void radtran_profile_reset(void *ptr);
 void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double *bytes_in,
                                double *bytes_out, double *bytes_tables_full, char *err);
 
+/* test hook: y[i] = the kernels' device exp(x[i]) (used where the reference calls exp) */
+void clima_test_device_exp(const int *n, const double *x, double *y, char *err);
+
 /* OpticalPropertiesResult (clima_radtran_types.f90:242-247), for parity checks:
  * tau,w0 (nz,ngauss,nw) and g,tau_band (nz,nw), column-major, TOA-first. */
 void radtran_opr_get(void *ptr, double *tau, double *w0, double *g, double *tau_band, char *err);

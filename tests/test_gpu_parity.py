@@ -68,6 +68,27 @@ def test_hip_extension_is_loaded(hip_lib):
     assert os.path.basename(lib.LIB_PATH) in maps
 
 
+def test_device_exp(hip_lib):
+    """The kernels' own exp (Cody-Waite + degree-13 polynomial) against libm: <= 2 ulp over the
+    argument ranges of this path, exact limits at the ends."""
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-760, 5, 200000), rng.uniform(-1e-3, 1e-3, 1000), -10 ** rng.uniform(-12, 7, 2000),
+                        rng.uniform(600, 720, 1000), [0.0, -0.0, -745.2, -1e9, 709.7, 710.5]])
+    y = np.empty_like(x)
+    err = C.create_string_buffer(1025)
+    dp = C.POINTER(C.c_double)
+    hip_lib.clima_test_device_exp(C.byref(C.c_int(len(x))), x.ctypes.data_as(dp), y.ctypes.data_as(dp), err)
+    assert err.value == b""
+    with np.errstate(over="ignore", under="ignore"):
+        ref = np.exp(x)
+    normal = (ref > 1e-300) & np.isfinite(ref)
+    ulp = np.abs(y[normal] - ref[normal]) / np.spacing(ref[normal])
+    assert ulp.max() <= 2.0, ulp.max()
+    assert np.all(y[ref == 0.0] == 0.0) and np.all(np.isinf(y[np.isinf(ref)]))
+    assert np.all(np.abs(y[~normal & (ref > 0) & np.isfinite(ref)] - ref[~normal & (ref > 0) & np.isfinite(ref)]) <= 1e-300)
+
+
 def test_config1_modern_earth_50_layers(O, small_tables):
     # BASELINE.json configs[0]: ModernEarth, 50 layers, 1 zenith angle, albedo 0.3
     from clima_amd import synthetic as S
