@@ -42,7 +42,7 @@ __device__ __forceinline__ double rcp_nr(double x) {
   return r;
 }
 
-// fast_exp(x) in ~20 f64 instructions (the ocml exp is ~2x that): k = rint(x*log2e),
+// exp(x) in ~20 f64 instructions (the ocml exp is ~2x that): k = rint(x*log2e),
 // r = x - k*ln2 (two-term Cody-Waite), degree-13 Taylor polynomial in r (|r| <= 0.35,
 // truncation 5e-18), scaled by 2^k.  Error <= 1 ulp over the arguments of this path;
 // underflows to 0 like exp().  tests/test_gpu_parity.py::test_device_exp checks it.
@@ -64,9 +64,12 @@ __device__ __forceinline__ double fast_exp(double x) {
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  int ki = (int)k;
-  ki = ki < -2000 ? -2000 : ki;                      // fast_exp(-inf) -> 0 without UB in the cast
-  return __builtin_ldexp(p, x > 709.0 ? 2000 : ki);
+  // scale by 2^k in two exact steps (2^k alone overflows before p*2^k does near exp's limit)
+  const int ki = (int)__builtin_fmin(__builtin_fmax(k, -2000.0), 2000.0);
+  const int k1 = ki >> 1, k2 = ki - k1;
+  const double s1 = __longlong_as_double((long long)(k1 + 1023) << 52);
+  const double s2 = __longlong_as_double((long long)(k2 + 1023) << 52);
+  return (p * s1) * s2;
 }
 
 // ten2power, src/clima_eqns.f90:75-80
@@ -1004,12 +1007,11 @@ __device__ __forceinline__ M7 m7_shfl_down(const M7 &a, int d) {
 constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
 
 template <int LMAX, bool SOLAR>
-__global__ __launch_bounds__(64 * TSW_COLS) void k_twostream_w(TwoStreamParams p) {
-  extern __shared__ __align__(16) double lds[];  // [3][TSW_COLS][nz+1] weighted level values
+__device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const int bin_local, double *lds) {
   const int nz = p.nz, ng = p.ng, nl = nz + 1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr bool solar = SOLAR;  // one launch per channel: blockIdx.x is the channel-local bin
-  const int ll = (solar ? p.sol_lo : p.ir_lo) + (int)blockIdx.x;
+  constexpr bool solar = SOLAR;
+  const int ll = (solar ? p.sol_lo : p.ir_lo) + bin_local;
   const int l = (solar ? p.sol_start : p.ir_start) + ll;  // opacity bin (radiate.f90:57)
   const int c_raw = blockIdx.y * TSW_COLS + wave;
   const bool col_on = c_raw < ng;
@@ -1311,6 +1313,15 @@ __global__ __launch_bounds__(64 * TSW_COLS) void k_twostream_w(TwoStreamParams p
   }
 }
 
+// one launch for both channels: blocks [0, n_sol) are solar bins (the heavier ones first),
+// blocks [n_sol, n_sol+n_ir) IR bins
+template <int LMAX>
+__global__ __launch_bounds__(64 * TSW_COLS) void k_twostream_w(TwoStreamParams p) {
+  extern __shared__ __align__(16) double lds[];  // [3][TSW_COLS][nz+1] weighted level values
+  if ((int)blockIdx.x < p.n_sol) twostream_w_body<LMAX, true>(p, (int)blockIdx.x, lds);
+  else twostream_w_body<LMAX, false>(p, (int)blockIdx.x - p.n_sol, lds);
+}
+
 static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
   // partial sums over g-point groups accumulate into zeroed outputs: one launch
   const size_t nl = (size_t)p.nz + 1;
@@ -1337,28 +1348,18 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
   const size_t lds = sizeof(double) * 3 * TSW_COLS * ((size_t)p.nz + 1);
   if (lds_bytes) *lds_bytes = lds;
   if (lds > 160 * 1024) return false;
-  if (p.n_sol + p.n_ir <= 0) return true;
+  const int grid = p.n_sol + p.n_ir;
+  if (grid <= 0) return true;
   if (groups > 1) ts_zero_outputs(p, s);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void *)k_twostream_w<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_twostream_w<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_twostream_w<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_twostream_w<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_twostream_w<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_twostream_w<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  const dim3 blk(64 * TSW_COLS);
-  // the heavier solar channel first; the two launches are independent of each other
-  if (p.n_sol > 0) {
-    const dim3 g(p.n_sol, groups);
-    if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4, true>), g, blk, lds, s, p);
-    else hipLaunchKernelGGL((k_twostream_w<8, true>), g, blk, lds, s, p);
-  }
-  if (p.n_ir > 0) {
-    const dim3 g(p.n_ir, groups);
-    if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4, false>), g, blk, lds, s, p);
-    else hipLaunchKernelGGL((k_twostream_w<8, false>), g, blk, lds, s, p);
-  }
+  const dim3 g(grid, groups), blk(64 * TSW_COLS);
+  if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4>), g, blk, lds, s, p);
+  else hipLaunchKernelGGL((k_twostream_w<8>), g, blk, lds, s, p);
   return true;
 }
 
