@@ -16,6 +16,19 @@
 
 namespace clima {
 
+// Diagnostic build only (-DCLIMA_STAMPS): s_memtime stamps of one wave, written to a buffer
+// nothing else reads.  The production build contains no stamp.
+#ifdef CLIMA_STAMPS
+#define STAMP(buf, slot)                                                          \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    if ((buf) && blockIdx.x == 100 && threadIdx.x == 0) (buf)[slot] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  } while (0)
+#else
+#define STAMP(buf, slot) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------
@@ -104,6 +117,7 @@ __device__ __forceinline__ int bracket(const double *xt, int n, double x) {
 // pair_reuse locally, so there is no inter-block dependency.
 // ------------------------------------------------------------------------------------
 constexpr int PREP_AXIS_MAX = 1024;
+constexpr int PREP_ZERO_BLOCKS = 32;  // blocks per output array cleared by the prep launch
 
 // source layer for interpolation: j, or j-1 when (j-1,j) is a reusable pair (types.f90:621-632)
 __device__ __forceinline__ int reuse_source(const PrepParams &p, int j) {
@@ -134,16 +148,34 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
       }
       c.foreign_col[j] = fc;
       c.src[j] = reuse_source(p, j);
-      // bin-independent weights of the continuum terms (types.f90:696-723)
-      for (int e = 0; e < p.nabs; e++) {
-        const int a = p.abs_a[e], b = p.abs_b[e];
-        double w;
-        if (p.abs_kind[e] == ABS_CIA) w = c.dens[a * nz + j] * c.dens[b * nz + j] * c.dz[j];
-        else if (p.abs_kind[e] == ABS_COLUMN) w = c.dens[a * nz + j] * c.dz[j];
-        else if (p.abs_kind[e] == ABS_H2O_SELF) w = c.dens[a * nz + j] * (c.dens[a * nz + j] * c.dz[j]);
-        else w = c.dens[a * nz + j] * fc;
-        c.absw[e * nz + j] = w;
+    }
+    return;
+  }
+  if ((int)blockIdx.x > p.nslots + p.nabs) {
+    // spare blocks clear the output spectra that the two-stream kernel accumulates into
+    const int zb = (int)blockIdx.x - (p.nslots + p.nabs + 1);
+    const int arr = zb / PREP_ZERO_BLOCKS, part = zb - arr * PREP_ZERO_BLOCKS;
+    double *dst = p.zero_ptr[arr];
+    const size_t n = p.zero_count[arr];
+    for (size_t i = (size_t)part * blockDim.x + threadIdx.x; i < n; i += (size_t)PREP_ZERO_BLOCKS * blockDim.x) dst[i] = 0.0;
+    return;
+  }
+  if ((int)blockIdx.x > p.nslots) {
+    // bin-independent weight of one continuum term for every layer (types.f90:696-723)
+    const int e = (int)blockIdx.x - p.nslots - 1;
+    const int a = p.abs_a[e], b = p.abs_b[e], kind = p.abs_kind[e];
+    for (int j = threadIdx.x; j < nz; j += blockDim.x) {
+      double w;
+      if (kind == ABS_CIA) w = c.dens[a * nz + j] * c.dens[b * nz + j] * c.dz[j];
+      else if (kind == ABS_COLUMN) w = c.dens[a * nz + j] * c.dz[j];
+      else if (kind == ABS_H2O_SELF) w = c.dens[a * nz + j] * (c.dens[a * nz + j] * c.dz[j]);
+      else {
+        double fc = 0.0;  // foreign column (:610-619)
+        for (int i = 0; i < p.nsp; i++)
+          if (i != p.LH2O) fc = fc + c.dens[i * nz + j] * c.dz[j];
+        w = c.dens[a * nz + j] * fc;
       }
+      c.absw[e * nz + j] = w;
     }
     return;
   }
@@ -172,7 +204,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
 }
 
 void launch_prep(const PrepParams &p, hipStream_t s) {
-  hipLaunchKernelGGL(k_prep, dim3(1 + p.nslots), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_prep, dim3(1 + p.nslots + p.nabs + p.nzero * PREP_ZERO_BLOCKS), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------
@@ -186,6 +218,10 @@ __device__ __forceinline__ double lerp1(const double *f, int i, double q) {
 }
 
 constexpr int OP_THREADS = 256;
+#ifdef CLIMA_STAMPS
+__device__ long long *g_stamp_buf = nullptr;
+__device__ int g_stamp_step = 0;
+#endif
 
 // Random-overlap resort + rebin for NG = 8 (k_rorr, types.f90:826-852), one lane per
 // (bin, layer).  x = current mixture tau_k(8), y = new species' k*col (8), in registers.
@@ -197,20 +233,26 @@ constexpr int OP_THREADS = 256;
 // cleared (relative perturbation <= 2^-46 = 1.4e-14, below the 3e-14 that the fast_exp() argument
 // rounding of the k-table interpolation already carries).  When y is ascending (the normal
 // case for k-distributions) the 8 runs of 8 keys are pre-sorted and only the merge tail of
-// the network runs.
+// the network runs; when x is ascending too (it is, up to rounding, after the first mixing
+// step) the first stage of every merge level is redundant as well: 295 of 543 exchanges.
 // Rebin (weights_to_bins + futils rebin, types.f90:846-847) as a stream over the sorted
 // keys: c = running sum of the sorted weights, S = running integral of the sorted step
 // function; whenever c passes an output edge E_k the integral up to that edge,
 // I_k = S + v*(E_k - c0), is written to the lane's private LDS slot k.  The new coefficients
 // are (I_k - I_{k-1}) / (E_k - E_{k-1}).
+template <bool MULTI>
 __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y)[8],
                                           double (*sI)[OP_THREADS], const int tid,
-                                          const double *s_wxy, const double *gE,
-                                          const double (&E)[9], double (&out)[8]) {
+                                          const double *s_wxy, const double *s_E,
+                                          const double (&E)[9], const double (&rW)[8],
+                                          double (&out)[8]) {
   double key[64];
-  bool ysorted = true;
+  bool ysorted = true, xsorted = true;
 #pragma unroll
-  for (int j = 0; j < 7; j++) ysorted = ysorted && (y[j] <= y[j + 1]);
+  for (int j = 0; j < 7; j++) {
+    ysorted = ysorted && (y[j] <= y[j + 1]);
+    xsorted = xsorted && (x[j] <= x[j + 1]);
+  }
 #pragma unroll
   for (int i = 0; i < 8; i++) {
 #pragma unroll
@@ -228,58 +270,107 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
     key[a] = lo_;                             \
     key[b] = hi_;                             \
   }
-  if (!__all(ysorted)) {
+  const bool ys = __all(ysorted), xys = ys && __all(xsorted);
+  if (!ys) {
 #define CE_FULL_HEAD
 #include "sort_network_64.inc"
 #undef CE_FULL_HEAD
   }
-#define CE_MERGE_TAIL
+  // merge levels; their first stage is redundant when x and y are both ascending
+  if (!xys) {
+#define CE_L8_FIRST
 #include "sort_network_64.inc"
-#undef CE_MERGE_TAIL
+#undef CE_L8_FIRST
+  }
+#define CE_L8_REST
+#include "sort_network_64.inc"
+#undef CE_L8_REST
+  if (!xys) {
+#define CE_L16_FIRST
+#include "sort_network_64.inc"
+#undef CE_L16_FIRST
+  }
+#define CE_L16_REST
+#include "sort_network_64.inc"
+#undef CE_L16_REST
+  if (!xys) {
+#define CE_L32_FIRST
+#include "sort_network_64.inc"
+#undef CE_L32_FIRST
+  }
+#define CE_L32_REST
+#include "sort_network_64.inc"
+#undef CE_L32_REST
 #undef CE
+  STAMP(g_stamp_buf, 30 + g_stamp_step);
   double S = 0.0, c0 = 0.0;
   int k = 1;                          // next output edge to pass: E[k]
   double bk = E[1], bn = E[2];        // E[k], E[k+1] (prefetched)
-  // weights_to_bins (clima_eqns.f90:43-54) on wxy(inds); the lookup runs one element ahead
-  double wn = s_wxy[(int)((unsigned long long)__double_as_longlong(key[0]) & 63ULL)];
+  // weights_to_bins (clima_eqns.f90:43-54) on wxy(inds): the LDS lookups run one batch of
+  // RB elements ahead of their use, so a batch pays one wait instead of one per element
+  constexpr int RB = 8;
+  double wn[RB];
 #pragma unroll
-  for (int p = 0; p < 64; p++) {
-    const unsigned long long kb = (unsigned long long)__double_as_longlong(key[p]);
-    const double v = __longlong_as_double((long long)(kb & ~63ULL));
-    const double w = wn;
-    if (p < 63) wn = s_wxy[(int)((unsigned long long)__double_as_longlong(key[p + 1]) & 63ULL)];
-    const double c1 = c0 + w;
-    if (c1 > bk) {                    // this element reaches past E[k]
-      do {
+  for (int u = 0; u < RB; u++) wn[u] = s_wxy[(int)((unsigned long long)__double_as_longlong(key[u]) & 63ULL)];
+#pragma unroll
+  for (int pb = 0; pb < 64; pb += RB) {
+    double wv[RB];
+#pragma unroll
+    for (int u = 0; u < RB; u++) wv[u] = wn[u];
+    if (pb + RB < 64) {
+#pragma unroll
+      for (int u = 0; u < RB; u++)
+        wn[u] = s_wxy[(int)((unsigned long long)__double_as_longlong(key[pb + RB + u]) & 63ULL)];
+    }
+#pragma unroll
+    for (int u = 0; u < RB; u++) {
+      const double v = key[pb + u];  // value with the pair index in its 6 low bits (<= 63 ulp)
+      const double w = wv[u];
+      const double c1 = c0 + w;
+      if (c1 > bk) {                    // this element reaches past E[k]
         sI[k - 1][tid] = __builtin_fma(v, bk - c0, S);
         k++;
         bk = bn;
-        bn = gE[k + 1];  // global (vmcnt) on purpose: keeps this lookup off the LDS wait counter
-      } while (c1 > bk);
+        if constexpr (MULTI) {
+          while (c1 > bk) {             // one element spanning a whole output bin: only possible
+            sI[k - 1][tid] = __builtin_fma(v, bk - c0, S);  // when max(wxy) > min(wbin)
+            k++;
+            bk = s_E[k];
+          }
+        }
+      }
+      bn = s_E[k + 1];  // refreshed unconditionally (unchanged if nothing was crossed): the
+                        // lookup is then consumed one element later instead of at the branch join
+      S = __builtin_fma(v, w, S);
+      c0 = c1;
     }
-    S = __builtin_fma(v, w, S);
-    c0 = c1;
   }
   for (; k <= 8; k++) sI[k - 1][tid] = S;  // edges at or beyond the total weight (rounding)
   double Ik[8];
 #pragma unroll
   for (int q = 0; q < 8; q++) Ik[q] = sI[q][tid];
-  out[0] = Ik[0] / (E[1] - E[0]);
+  out[0] = Ik[0] * rW[0];  // rW = 1/(E_{k+1}-E_k), formed once per kernel
 #pragma unroll
-  for (int q = 1; q < 8; q++) out[q] = (Ik[q] - Ik[q - 1]) / (E[q + 1] - E[q]);
+  for (int q = 1; q < 8; q++) out[q] = (Ik[q] - Ik[q - 1]) * rW[q];
 }
 
+template <bool MULTI>
 __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   constexpr int NG = 8;
   __shared__ double sI[NG][OP_THREADS];  // per-lane private slots (slot-major: conflict-free)
   __shared__ double s_wxy[NG * NG];
+  __shared__ double s_E[NG + 4];  // output edges followed by +inf sentinels
   const int tid = threadIdx.x;
   if (tid < NG * NG) s_wxy[tid] = p.wxy[tid];
+  if (tid < NG + 4) s_E[tid] = p.wbin_e_pad[tid];
   double E[NG + 1], wbin[NG];  // wave-uniform: scalar loads
 #pragma unroll
   for (int k = 0; k < NG + 1; k++) E[k] = p.wbin_e[k];
 #pragma unroll
   for (int k = 0; k < NG; k++) wbin[k] = p.wbin[k];
+  double rW[NG];
+#pragma unroll
+  for (int k = 0; k < NG; k++) rW[k] = 1.0 / (E[k + 1] - E[k]);
   __syncthreads();
 
   const int nz = p.nz;
@@ -294,6 +385,7 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   const bool reuse = c.src[j] != j;
   const double dzj = c.dz[j];
 
+  STAMP(p.stamps, 0);
   // ---- Rayleigh (:686-693)
   double tausg = 0.0;
 #pragma unroll 4
@@ -353,6 +445,7 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   gt = gt + TINY * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
   gt = fmin(gt, MAX_GT);
 
+  STAMP(p.stamps, 1);
   // ---- k-distributions (:649-662) and random-overlap mixing (k_rorr :816-854)
   double tk[NG];  // tau_k of the running mixture
 #pragma unroll
@@ -384,12 +477,16 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
       const double fx2 = p1 * f12[g] + q1 * f22[g];
       kc[g] = ten2power(p2 * fx1 + q2 * fx2) * col;  // :818 / :828
     }
+    STAMP(p.stamps, 2 + 3 * s);
     if (s == 0) {
 #pragma unroll
       for (int g = 0; g < NG; g++) tk[g] = kc[g];
     } else if (!(p.debug_skip & 1)) {
+#ifdef CLIMA_STAMPS
+      if (blockIdx.x == 100 && threadIdx.x == 0) { g_stamp_buf = p.stamps; g_stamp_step = s; }
+#endif
       double out[NG];
-      rorr_mix8(tk, kc, sI, tid, s_wxy, p.wbin_e_pad, E, out);
+      rorr_mix8<MULTI>(tk, kc, sI, tid, s_wxy, s_E, E, rW, out);
       // pair_reuse: the second layer of a pair copies the first layer's rebinned
       // mixture (:833-834).  Layer j-1 of the same bin lives in lane-1 (nz even).
 #pragma unroll
@@ -397,8 +494,10 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
         const double prev = __shfl_up(out[g], 1);
         tk[g] = reuse ? prev : out[g];
       }
+      STAMP(p.stamps, 4 + 3 * s);
     }
   }
+  STAMP(p.stamps, 20);
 
   // ---- totals (:856-886)
   if (valid) {
@@ -424,7 +523,8 @@ bool launch_opacity(const OpacityParams &p, hipStream_t s) {
   const long total = (long)p.nbins * p.nz;
   if (total <= 0) return true;
   const int grid = (int)((total + OP_THREADS - 1) / OP_THREADS);
-  hipLaunchKernelGGL(k_opacity8, dim3(grid), dim3(OP_THREADS), 0, s, p);
+  if (p.multi_edge) hipLaunchKernelGGL(k_opacity8<true>, dim3(grid), dim3(OP_THREADS), 0, s, p);
+  else hipLaunchKernelGGL(k_opacity8<false>, dim3(grid), dim3(OP_THREADS), 0, s, p);
   return true;
 }
 
@@ -1340,7 +1440,9 @@ static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
 }
 
 // wave-per-column launcher; false when nz needs more than 8 layers per lane
-bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
+int twostream_w_groups(int ng) { return (ng + TSW_COLS - 1) / TSW_COLS; }
+
+bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed) {
   const int lmax = (p.nz + 63) / 64;
   if (lmax > 8) return false;
   const int groups = (p.ng + TSW_COLS - 1) / TSW_COLS;
@@ -1350,7 +1452,7 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
   if (lds > 160 * 1024) return false;
   const int grid = p.n_sol + p.n_ir;
   if (grid <= 0) return true;
-  if (groups > 1) ts_zero_outputs(p, s);
+  if (groups > 1 && !zeroed) ts_zero_outputs(p, s);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void *)k_twostream_w<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -128,6 +128,9 @@ struct Radtran {
   DevBuf<double> d_log10P, d_cols, d_foreign, d_q, d_absw;
   std::vector<AbsEntry> abs_entries;  // continuum terms in the reference's summation order
   DevBuf<int> d_src, d_ix, d_err;
+#ifdef CLIMA_STAMPS
+  DevBuf<long long> d_stamps;
+#endif
   double *h_col = nullptr;  // pinned staging
   size_t col_count = 0;
   bool column_has_particles = false;
@@ -354,6 +357,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   upload_fields(r);
   const int nz = r->nz;
   ColumnDev col = column_dev(r);
+  bool pre_zeroed = false;
   if (compute_opacity) {
     PrepParams pp;
     std::memset(&pp, 0, sizeof(pp));
@@ -365,6 +369,27 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     for (int e = 0; e < pp.nabs; e++) { pp.abs_kind[e] = r->abs_entries[e].kind; pp.abs_a[e] = r->abs_entries[e].a; pp.abs_b[e] = r->abs_entries[e].b; }
     pp.col = col;
     pp.call_id = ++r->call_id;
+    {  // when the wave-per-column two-stream kernel will add two g-point groups into its
+       // outputs, let spare blocks of this launch clear them (saves a launch)
+      const char *mode = getenv("CLIMA_HIP_TS_MODE");
+      const bool wave_mode = !(mode && std::strcmp(mode, "block") == 0) && (nz + 63) / 64 <= 8;
+      pre_zeroed = false;
+      if (wave_mode && twostream_w_groups(r->ng) == 2) {
+        const size_t nl = (size_t)nz + 1;
+        int n = 0;
+        if (r->ir_n > 0) {
+          pp.zero_ptr[n] = r->wrk_ir.fup_a.p + (size_t)r->ir_lo * nl; pp.zero_count[n++] = nl * r->ir_n;
+          pp.zero_ptr[n] = r->wrk_ir.fdn_a.p + (size_t)r->ir_lo * nl; pp.zero_count[n++] = nl * r->ir_n;
+        }
+        if (compute_solar && r->sol_n > 0) {
+          pp.zero_ptr[n] = r->wrk_sol.fup_a.p + (size_t)r->sol_lo * nl; pp.zero_count[n++] = nl * r->sol_n;
+          pp.zero_ptr[n] = r->wrk_sol.fdn_a.p + (size_t)r->sol_lo * nl; pp.zero_count[n++] = nl * r->sol_n;
+          pp.zero_ptr[n] = r->wrk_sol.amean.p + (size_t)r->sol_lo * nl; pp.zero_count[n++] = nl * r->sol_n;
+        }
+        pp.nzero = n;
+        pre_zeroed = true;
+      }
+    }
     { KernelTimer t(r, 0); launch_prep(pp, r->stream); t.stop(); }
 
     OpacityParams op;
@@ -382,6 +407,10 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
       op.part[i] = PartDev{r->part[i]->d_w0.p, r->part[i]->d_qext.p, r->part[i]->d_gt.p, r->part[i]->p_ind, r->part[i]->nrad, r->part_slot[i]};
     op.wbin = r->d_wbin.p; op.wbin_e = r->d_wbin_e.p; op.wxy = r->d_wxy.p; op.wbin_e_pad = r->d_wbin_e_pad.p;
     op.col = col;
+    op.multi_edge = (*std::max_element(r->wxy.begin(), r->wxy.end()) > *std::min_element(r->wbin.begin(), r->wbin.end())) ? 1 : 0;
+#ifdef CLIMA_STAMPS
+    op.stamps = r->d_stamps.p;
+#endif
     op.tau = r->d_tau.p; op.w0 = r->d_w0.p; op.g = r->d_g.p; op.tau_band = r->d_tau_band.p;
     {
       KernelTimer t(r, 1);
@@ -416,7 +445,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     // default: wave-per-column kernel; CLIMA_HIP_TS_MODE=block selects the workgroup-per-bin form
     const char *mode = getenv("CLIMA_HIP_TS_MODE");
     bool ok = false;
-    if (!(mode && std::strcmp(mode, "block") == 0)) ok = launch_twostream_w(ts, r->stream, &r->ts_lds);
+    if (!(mode && std::strcmp(mode, "block") == 0)) ok = launch_twostream_w(ts, r->stream, &r->ts_lds, pre_zeroed);
     if (!ok) ok = launch_twostream(ts, r->stream, &r->ts_lds);
     if (!ok)
       throw HipFail{"nz*ngauss = " + std::to_string(nz * r->ng) + " exceeds what the two-stream kernels can stage"};
@@ -735,6 +764,9 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   r->d_absw.alloc((size_t)std::max<size_t>(1, r->abs_entries.size()) * nz);
   r->d_src.alloc(nz); r->d_ix.alloc((size_t)std::max(1, r->nslots) * nz); r->d_q.alloc((size_t)std::max(1, r->nslots) * nz);
   r->d_err.alloc(1); r->d_err.zero();
+#ifdef CLIMA_STAMPS
+  r->d_stamps.alloc(64); r->d_stamps.zero();
+#endif
   r->d_tau.alloc((size_t)nw * ng * nz); r->d_w0.alloc((size_t)nw * ng * nz);
   r->d_g.alloc((size_t)nw * nz); r->d_tau_band.alloc((size_t)nw * nz);
   r->d_tau.zero(); r->d_w0.zero(); r->d_g.zero(); r->d_tau_band.zero();
@@ -964,6 +996,14 @@ void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double 
   *bytes_in = 8.0 * (nz * (3.0 + r->nsp + 2.0 * r->np) + 2.0 * nw + nzen * 2.0 + r->sol.nw);
   *bytes_out = 8.0 * ((2.0 * (nz + 1) + nz) * r->ir.nw + (3.0 * (nz + 1) + nz) * r->sol.nw + 5.0 * (nz + 1));
 }
+
+#ifdef CLIMA_STAMPS
+extern "C" void clima_debug_stamps(void *ptr, long long *out) {
+  Radtran *r = as_rad(ptr);
+  (void)hipStreamSynchronize(r->stream);
+  (void)hipMemcpy(out, r->d_stamps.p, 64 * sizeof(long long), hipMemcpyDeviceToHost);
+}
+#endif
 
 void radtran_opr_get(void *ptr, double *tau, double *w0, double *g, double *tau_band, char *err) {
   clear_err(err);

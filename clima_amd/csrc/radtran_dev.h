@@ -104,6 +104,8 @@ struct OpacityParams {
   const double *wbin_e_pad;               // wbin_e followed by +inf sentinels (edge stream of the rebin)
   ColumnDev col;
   double *tau, *w0, *g, *tau_band;        // opr
+  long long *stamps;                      // diagnostic build only (-DCLIMA_STAMPS); null otherwise
+  int multi_edge;                         // max(wxy) > min(wbin): a sorted element may span several output edges
 };
 
 struct PrepParams {
@@ -112,6 +114,9 @@ struct PrepParams {
   SlotDev slots[MAX_SLOTS];
   int nabs;
   int abs_kind[MAX_ABS], abs_a[MAX_ABS], abs_b[MAX_ABS];
+  int nzero;                 // output arrays cleared by spare blocks of the prep launch
+  double *zero_ptr[6];
+  size_t zero_count[6];
   ColumnDev col;
 };
 
@@ -160,7 +165,8 @@ void launch_prep(const PrepParams &p, hipStream_t s);
 // returns false when ng is unsupported by the compiled kernels
 bool launch_opacity(const OpacityParams &p, hipStream_t s);
 bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
-bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
+bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed);
+int twostream_w_groups(int ng);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
 int integrate_chunks(int nbins);
 void launch_f_total(int nz, const double *flux_n, double *f_total, hipStream_t s);

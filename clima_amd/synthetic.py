@@ -103,7 +103,7 @@ def make_tables(nw=1000, ng=8, nP=20, nT=20, species=MODERN_EARTH_SPECIES,
                 ray_species=("CO2", "O2", "N2", "CH4", "H2O"),
                 pxs_species=("H2O", "CO2", "O2", "O3", "CH4"),
                 particles=("HCaer1",), water_continuum=True, nT_cia=10, nrad=20,
-                star="sun_now", seed=SEED, sorted_k=True, sol_frac=0.6, ir_frac=0.4):
+                star="sun_now", seed=SEED, sorted_k=True, sol_frac=0.6, ir_frac=0.4, weights=None):
     """Synthetic `TableSet`.  `sorted_k=False` scrambles the g ordering of
     the k-coefficients to exercise the general (unsorted) resort path."""
     rng = np.random.default_rng(seed)
@@ -113,7 +113,7 @@ def make_tables(nw=1000, ng=8, nP=20, nT=20, species=MODERN_EARTH_SPECIES,
     t.wavl = nominal_wavl(nw)
     lam = np.sqrt(t.wavl[:-1] * t.wavl[1:])  # bin centres, nm
     x = np.log10(lam)  # 2..6
-    weights = gauss_weights01(ng)
+    weights = gauss_weights01(ng) if weights is None else np.asarray(weights, dtype=float)
     log10P = np.linspace(-6.0, 2.0, nP)
     temp = np.linspace(50.0, 1000.0, nT)
     gq = np.cumsum(weights) - 0.5 * weights  # g mid-points

@@ -144,6 +144,16 @@ def test_unsorted_k_coefficients_use_full_network(O):
     _compare(r, o, S.modern_earth_column(31))
 
 
+def test_uneven_g_weights_multi_edge_rebin(O):
+    # split quadrature with tiny weights near g -> 1 (as real k-tables have): a sorted element can
+    # then be wider than an output bin and cross several edges at once (max(wxy) > min(wbin))
+    from clima_amd import synthetic as S
+    w = np.array([0.30, 0.28, 0.20, 0.12, 0.06, 0.025, 0.011, 0.004])
+    tb = S.modern_earth_tables(nw=16, seed=77, weights=w / w.sum())
+    r, o = _pair(O, tb, 33, 2, 0.3)
+    _compare(r, o, S.modern_earth_column(33))
+
+
 def test_ties_and_zero_columns(O, small_tables):
     # a species with zero abundance gives 8-fold ties in every resort
     from clima_amd import synthetic as S
@@ -168,6 +178,31 @@ def test_early_mars_cia_heavy(O):
     tb = S.early_mars_tables(nw=60)
     r, o = _pair(O, tb, 200, 4, 0.2, photon_scale_factor=0.4286)
     _compare(r, o, S.early_mars_column(200))
+
+
+def test_config5_500_layers(O):
+    # BASELINE.json configs[4] column shape (500 layers: 8 layers per lane in the two-stream kernel)
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=20, seed=55)
+    r, o = _pair(O, tb, 500, 4, 0.15)
+    _compare(r, o, S.modern_earth_column(500))
+
+
+def test_config4_perturbed_columns(O, small_tables):
+    # BASELINE.json configs[3]: perturbed ModernEarth columns (T-P and mixing-ratio sweep),
+    # here a handful of them through one handle, one after the other
+    from clima_amd import synthetic as S
+    r, o = _pair(O, small_tables, 50, 2, 0.15)
+    for col in S.perturbed_columns(6, nz=50, seed=7):
+        _compare(r, o, col)
+
+
+def test_workgroup_per_bin_kernel_agrees(O, small_tables, monkeypatch):
+    # the LDS-staged workgroup-per-bin two-stream kernel (fallback form) gives the same answers
+    from clima_amd import synthetic as S
+    monkeypatch.setenv("CLIMA_HIP_TS_MODE", "block")
+    r, o = _pair(O, small_tables, 50, 4, 0.3)
+    _compare(r, o, S.modern_earth_column(50))
 
 
 def test_state_carried_between_calls(O, small_tables):

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Developer diagnostic: per-phase s_memtime stamps of one opacity wave (needs the
+-DCLIMA_STAMPS build, clima_amd/csrc/libclima_radtran_hip_stamps.so)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from clima_amd import lib
+lib.LIB_PATH = lib.LIB_PATH.replace("libclima_radtran_hip.so", "libclima_radtran_hip_stamps.so")
+from clima_amd import synthetic as S
+from clima_amd.radtran import Radtran
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+tb = S.modern_earth_tables()
+col = S.modern_earth_column(200)
+r = Radtran(tb, 200, 8, 0.15)
+if world > 1: r.set_bin_shard(0, world)
+r.upload_column(*col.args())
+for _ in range(3): r.radiate_resident()
+r.synchronize()
+out = (C.c_longlong * 64)()
+r._L.clima_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+r._L.clima_debug_stamps(r._ptr, out)
+s = list(out)
+t0 = s[0]
+print("continuum        %7d" % (s[1] - s[0]))
+prev = s[1]
+for sp in range(5):
+    a = s[2 + 3 * sp]
+    print("species %d interp %7d" % (sp, a - prev))
+    if sp > 0:
+        print("   sort          %7d" % (s[30 + sp] - a))
+        print("   rebin         %7d" % (s[4 + 3 * sp] - s[30 + sp]))
+        prev = s[4 + 3 * sp]
+    else:
+        prev = a
+print("epilogue         %7d" % (s[20] - prev))
+print("total            %7d  (s_memtime ticks = shader cycles)" % (s[20] - s[0]))
