@@ -373,6 +373,9 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   for (int k = 0; k < NG; k++) rW[k] = 1.0 / (E[k + 1] - E[k]);
   __syncthreads();
 
+#ifdef CLIMA_STAMPS
+  const long long wt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int nz = p.nz;
   const long total = (long)p.nbins * nz;
   const ColumnDev &c = p.col;
@@ -391,29 +394,30 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
 #pragma unroll 4
   for (int i = 0; i < p.nray; i++) tausg = tausg + p.ray[i].data[l] * c.cols[p.ray[i].sp1 * nz + j];
   // ---- continuum absorption: CIA, photolysis/absorption, H2O continuum (:665-677, :696-723).
-  // Entries are processed four at a time with every load of the batch issued before the
+  // Entries are processed eight at a time with every load of the batch issued before the
   // first use, so the dependent index -> table round trips overlap instead of queueing.
   double taua = 0.0;
-  for (int e0 = 0; e0 < p.nabs; e0 += 4) {
-    int ixx[4];
-    double qq[4], ww[4];
+  constexpr int AB = 8;
+  for (int e0 = 0; e0 < p.nabs; e0 += AB) {
+    int ixx[AB];
+    double qq[AB], ww[AB];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < AB; u++) {
       const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
       ixx[u] = c.ix[x.slot * nz + j];
       qq[u] = c.q[x.slot * nz + j];
       ww[u] = c.absw[min(e0 + u, p.nabs - 1) * nz + j];
     }
-    double v0[4], v1[4];
+    double v0[AB], v1[AB];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < AB; u++) {
       const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
       const double *base = x.data + (x.nT ? (size_t)l * x.nT + ixx[u] : (size_t)l);
       v0[u] = base[0];
       v1[u] = base[x.nT ? 1 : 0];
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < AB; u++) {
       if (e0 + u < p.nabs) {
         const AbsEntry &x = p.abs[e0 + u];
         double sgm = v0[u];
@@ -498,6 +502,13 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
     }
   }
   STAMP(p.stamps, 20);
+#ifdef CLIMA_STAMPS
+  if (p.stamps && (tid & 63) == 0) {
+    const long w = (long)blockIdx.x * (OP_THREADS / 64) + (tid >> 6);
+    p.stamps[64 + 2 * w] = wt0;
+    p.stamps[64 + 2 * w + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 
   // ---- totals (:856-886)
   if (valid) {
@@ -1149,7 +1160,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
     tcum = __shfl_up(incl, 1);
     if (lane == 0) tcum = 0.0;
     double wsum = 0.0, dir0 = 0.0;
-    for (int z = 0; z < p.nzen; z++) { wsum = wsum + p.zen_w[z]; dir0 = dir0 + p.zen_w[z] * p.zen_u[z]; }
+    for (int z = 0; z < p.nzen; z++) { wsum = wsum + p.zen_w_v[z]; dir0 = dir0 + p.zen_w_v[z] * p.zen_u_v[z]; }
     lvl0_dn = dir0;   // direct(1) = u0 (:73)
     lvl0_am = wsum;   // direct(1)/u0 = 1
     Rsfc = p.albedo[ll];
@@ -1201,7 +1212,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 #pragma unroll
           for (int z = 0; z < NZMAX; z++) {
             if (z < p.nzen) {
-              const double u0 = p.zen_u[z], wz = p.zen_w[z], iu = p.zen_iu[z];
+              const double u0 = p.zen_u_v[z], wz = p.zen_w_v[z], iu = p.zen_iu_v[z];
               const double gam3 = (1.0 - sqrt3 * gtp * u0) / 2.0;
               const double gam4 = 1.0 - gam3;
               const double facp = w0p * ((gam1 - iu) * gam3 + gam4 * gam2);
@@ -1222,7 +1233,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
             }
           }
           for (int z = NZMAX; z < p.nzen; z++) {  // more zenith angles than the carried set: recompute
-            const double u0 = p.zen_u[z], wz = p.zen_w[z], iu = p.zen_iu[z];
+            const double u0 = p.zen_u_v[z], wz = p.zen_w_v[z], iu = p.zen_iu_v[z];
             const double gam3 = (1.0 - sqrt3 * gtp * u0) / 2.0;
             const double gam4 = 1.0 - gam3;
             const double facp = w0p * ((gam1 - iu) * gam3 + gam4 * gam2);

@@ -434,6 +434,9 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   ts.T = col.T; ts.T_surface = col.T_surface;
   ts.emissivity = r->d_emis.p; ts.has_hard_surface = r->has_hard_surface ? 1 : 0; ts.ir_tau_min = r->ir_tau_min;
   ts.nzen = (int)r->zenith_u.size(); ts.zen_u = r->d_zen_u.p; ts.zen_w = r->d_zen_w.p; ts.zen_iu = r->d_zen_iu.p;
+  for (int z = 0; z < ts.nzen && z < MAX_ZEN; z++) {
+    ts.zen_u_v[z] = r->zenith_u[z]; ts.zen_w_v[z] = r->zenith_w[z]; ts.zen_iu_v[z] = 1.0 / r->zenith_u[z];
+  }
   ts.albedo = r->d_albedo.p; ts.photons_sol = r->d_photons.p;
   ts.photon_scale_factor = r->photon_scale_factor; ts.diurnal_fac = r->diurnal_fac;
   ts.am_f1 = r->d_am_f1.p; ts.am_f2 = r->d_am_f2.p; ts.am_dw = r->d_am_dw.p;
@@ -445,7 +448,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     // default: wave-per-column kernel; CLIMA_HIP_TS_MODE=block selects the workgroup-per-bin form
     const char *mode = getenv("CLIMA_HIP_TS_MODE");
     bool ok = false;
-    if (!(mode && std::strcmp(mode, "block") == 0)) ok = launch_twostream_w(ts, r->stream, &r->ts_lds, pre_zeroed);
+    if (!(mode && std::strcmp(mode, "block") == 0) && ts.nzen <= MAX_ZEN) ok = launch_twostream_w(ts, r->stream, &r->ts_lds, pre_zeroed);
     if (!ok) ok = launch_twostream(ts, r->stream, &r->ts_lds);
     if (!ok)
       throw HipFail{"nz*ngauss = " + std::to_string(nz * r->ng) + " exceeds what the two-stream kernels can stage"};
@@ -765,7 +768,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   r->d_src.alloc(nz); r->d_ix.alloc((size_t)std::max(1, r->nslots) * nz); r->d_q.alloc((size_t)std::max(1, r->nslots) * nz);
   r->d_err.alloc(1); r->d_err.zero();
 #ifdef CLIMA_STAMPS
-  r->d_stamps.alloc(64); r->d_stamps.zero();
+  r->d_stamps.alloc(64 + 2 * 8192); r->d_stamps.zero();
 #endif
   r->d_tau.alloc((size_t)nw * ng * nz); r->d_w0.alloc((size_t)nw * ng * nz);
   r->d_g.alloc((size_t)nw * nz); r->d_tau_band.alloc((size_t)nw * nz);
@@ -1001,7 +1004,7 @@ void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double 
 extern "C" void clima_debug_stamps(void *ptr, long long *out) {
   Radtran *r = as_rad(ptr);
   (void)hipStreamSynchronize(r->stream);
-  (void)hipMemcpy(out, r->d_stamps.p, 64 * sizeof(long long), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(out, r->d_stamps.p, (64 + 2 * 8192) * sizeof(long long), hipMemcpyDeviceToHost);
 }
 #endif
 

@@ -26,6 +26,7 @@ namespace clima {
 constexpr int MAX_K = 8;      // k-distribution species
 constexpr int MAX_XS = 16;    // per Xsection kind
 constexpr int MAX_PART = 4;   // particle species
+constexpr int MAX_ZEN = 16;   // zenith angles passed by value to the two-stream kernel
 constexpr int MAX_SLOTS = 2 * MAX_K + 2 * MAX_XS + 1 + MAX_PART;
 
 // src/clima_const.f90:9-21
@@ -137,7 +138,9 @@ struct TwoStreamParams {
   double ir_tau_min;
   // solar
   int nzen;
-  const double *zen_u, *zen_w, *zen_iu;    // cos(zenith), weights, 1/cos
+  const double *zen_u, *zen_w, *zen_iu;    // cos(zenith), weights, 1/cos (device arrays)
+  // the same by value (kernarg segment -> scalar loads in the zenith loop); valid for nzen <= MAX_ZEN
+  double zen_u_v[MAX_ZEN], zen_w_v[MAX_ZEN], zen_iu_v[MAX_ZEN];
   const double *albedo;                    // [nw_sol]
   const double *photons_sol;               // [nw_sol], unscaled
   double photon_scale_factor, diurnal_fac;
