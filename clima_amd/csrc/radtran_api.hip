@@ -151,7 +151,7 @@ struct Radtran {
   int op_lo = 0, op_n = 0, ir_lo = 0, ir_n = 0, sol_lo = 0, sol_n = 0;
   // stream + profiling
   hipStream_t stream = nullptr;
-  bool profile = false;
+  int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (k_opacity) only
   struct Ev { hipEvent_t a, b; int id; };
   std::vector<Ev> pending;
   std::vector<hipEvent_t> pool;
@@ -303,15 +303,16 @@ struct KernelTimer {
   Radtran *r;
   int id;
   hipEvent_t a = nullptr, b = nullptr;
+  bool on() const { return r->profile == 1 || (r->profile == 2 && id == 1); }
   KernelTimer(Radtran *r_, int id_) : r(r_), id(id_) {
-    if (r->profile) {
+    if (on()) {
       a = get_event(r);
       b = get_event(r);
       HIPCHK(hipEventRecord(a, r->stream));
     }
   }
   void stop() {
-    if (r->profile) {
+    if (on()) {
       HIPCHK(hipEventRecord(b, r->stream));
       r->pending.push_back({a, b, id});
     }
@@ -932,7 +933,7 @@ void radtran_stream_get(void *ptr, void **stream) {
 
 void radtran_profile_set(void *ptr, const int *enable) {
   Radtran *r = as_rad(ptr);
-  if (r) r->profile = (*enable != 0);
+  if (r) r->profile = (*enable == 2) ? 2 : (*enable != 0 ? 1 : 0);
 }
 void radtran_profile_reset(void *ptr) {
   Radtran *r = as_rad(ptr);

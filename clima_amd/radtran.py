@@ -258,7 +258,9 @@ class Radtran:
         return p.value
 
     def profile(self, enable=True):
-        self._L.radtran_profile_set(self._ptr, _i(1 if enable else 0))
+        """HIP events on the library stream: True/1 around every kernel, 2 around the dominant
+        kernel (k_opacity) only (two event records per call instead of eight), False/0 off."""
+        self._L.radtran_profile_set(self._ptr, _i(2 if enable == 2 and enable is not True else (1 if enable else 0)))
 
     def profile_reset(self):
         self._L.radtran_profile_reset(self._ptr)

@@ -125,9 +125,10 @@ void radtran_bin_shard_get(void *ptr, int *op_lo, int *op_n, int *ir_lo, int *ir
 void radtran_finish_reduced(void *ptr, char *err);
 /* HIP stream the handle launches on (for callers that order other work against it) */
 void radtran_stream_get(void *ptr, void **stream);
-/* per-kernel device time (HIP events on the handle's stream).  enable!=0 records events
- * around every kernel; kernel_time_get returns accumulated ms and launch count for
- * kernel id (0 prep, 1 opacity, 2 twostream, 3 integrate) and resets nothing. */
+/* per-kernel device time (HIP events on the handle's stream).  enable = 1 records events
+ * around every kernel, enable = 2 around the dominant kernel (id 1, opacity) only, 0 turns
+ * them off; kernel_time_get returns accumulated ms and launch count for kernel id
+ * (0 prep, 1 opacity, 2 twostream, 3 integrate) and resets nothing. */
 void radtran_profile_set(void *ptr, const int *enable);
 void radtran_kernel_time_get(void *ptr, const int *kernel_id, double *ms_total, int *launches,
                              char *err);

@@ -70,6 +70,13 @@ def run(name, tables, col, nz, nzen, albedo, reps=5, **scalars):
     r.synchronize()
     dt = (time.time() - t0) / reps
     print("  GPU (events off) %.1f us/call (%.0f calls/s)" % (dt * 1e6, 1.0 / dt))
+    # PCIe-inclusive: host arrays in, ISR/OLR out through radtran_toa_fluxes_wrapper, synchronous
+    args = col.args()
+    t0 = time.time()
+    for _ in range(reps):
+        r.TOA_fluxes(*args)
+    dt = (time.time() - t0) / reps
+    print("  host API (PCIe-inclusive, synchronous TOA_fluxes) %.1f us/call (%.0f calls/s)" % (dt * 1e6, 1.0 / dt))
     print("  bytes:", r.algorithmic_bytes())
 
 
