@@ -529,9 +529,169 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------
+// k_opacity_generic: any g-point count ng <= OPG_MAX_NG (the k-distribution settings allow
+// `new_num_k_bins` other than 8).  One wave per (bin, layer); the ng*ng sums of the
+// random-overlap step live in LDS and are sorted by a wave-cooperative bitonic network on
+// (value, pair index) -- lexicographic, i.e. exactly the stable rank of mrgrnk
+// (types.f90:840) -- then weights_to_bins (clima_eqns.f90:43-54) runs serially in rank
+// order and every output g-point is rebinned by its own lane with the overlap sum of the
+// futils rebin (types.f90:847).  Same arithmetic order as the reference; this is the
+// completeness path, k_opacity8 is the tuned one.
+// ------------------------------------------------------------------------------------
+constexpr int OPG_MAX_NG = 32;
+
+__global__ __launch_bounds__(64) void k_opacity_generic(OpacityParams p, int N2) {
+  extern __shared__ __align__(16) double sm[];
+  const int ng = p.ng, n2 = ng * ng, nz = p.nz;
+  double *s_key = sm;                 // [N2]
+  double *s_cum = s_key + N2;         // [n2 + 1] cumulative sorted weights
+  double *s_tk = s_cum + (n2 + 1);    // [ng] running mixture
+  double *s_kc = s_tk + ng;           // [ng] new species
+  double *s_out = s_kc + ng;          // [ng]
+  int *s_idx = (int *)(s_out + ng);   // [N2]
+  const int lane = threadIdx.x;
+  const ColumnDev &c = p.col;
+  const long t = blockIdx.x;
+  const int l = p.bin_lo + (int)(t / nz);
+  const int j = (int)(t % nz);   // ground-first layer
+  const int n = nz - 1 - j;      // TOA-first index
+  const double dzj = c.dz[j];
+  // the second layer of a reused pair takes the rebinned mixture of the first (:833-834);
+  // with nk >= 2 its final mixture depends on the first layer's inputs only
+  const int jk = (p.nk >= 2) ? c.src[j] : j;
+
+  // ---- wave-uniform terms (same statements as k_opacity8)
+  double tausg = 0.0;
+  for (int i = 0; i < p.nray; i++) tausg = tausg + p.ray[i].data[l] * c.cols[p.ray[i].sp1 * nz + j];
+  double taua = 0.0;
+  for (int e = 0; e < p.nabs; e++) {
+    const AbsEntry &x = p.abs[e];
+    double sgm;
+    if (x.nT) {
+      const int ix = c.ix[x.slot * nz + j];
+      const double q = c.q[x.slot * nz + j];
+      const double *base = x.data + (size_t)l * x.nT + ix;
+      sgm = ten2power((1.0 - q) * base[0] + q * base[1]);
+    } else {
+      sgm = x.data[l];
+    }
+    taua = taua + sgm * c.absw[e * nz + j];
+  }
+  const double tauc = TINY, tausc = TINY * TINY;
+  double tausp = 0.0, taup = 0.0;
+  double tausp_1[MAX_PART], gtp[MAX_PART];
+  for (int i = 0; i < p.npart; i++) {
+    const PartDev &pt = p.part[i];
+    const int ix = c.ix[pt.slot * nz + j];
+    const double q = c.q[pt.slot * nz + j];
+    const double w0p = lerp1(pt.w0 + (size_t)l * pt.nrad, ix, q);
+    const double qext = lerp1(pt.qext + (size_t)l * pt.nrad, ix, q);
+    gtp[i] = lerp1(pt.gt + (size_t)l * pt.nrad, ix, q);
+    const double rr = c.radii[pt.p_ind * nz + j];
+    const double taup_1 = qext * PI * (rr * rr) * c.pdens[pt.p_ind * nz + j] * dzj;
+    taup = taup + taup_1;
+    tausp_1[i] = w0p * taup_1;
+    tausp = tausp + tausp_1[i];
+  }
+  double gt = 0.0;
+  for (int i = 0; i < p.npart; i++) gt = gt + gtp[i] * tausp_1[i] / fmax(TAU_MIN, (tausp + tausg + tausc));
+  gt = gt + TINY * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
+  gt = fmin(gt, MAX_GT);
+
+  // ---- k-distributions and random-overlap mixing
+  for (int s = 0; s < p.nk; s++) {
+    const KDev &kd = p.k[s];
+    if (lane < ng) {
+      const int iP = c.ix[kd.slotP * nz + jk], iT = c.ix[kd.slotT * nz + jk];
+      const double q1 = c.q[kd.slotP * nz + jk], q2 = c.q[kd.slotT * nz + jk];
+      const double p1 = 1.0 - q1, p2 = 1.0 - q2;
+      const double *f11 = kd.log10k + (size_t)l * kd.nT * kd.nP * ng + ((size_t)iT * kd.nP + iP) * ng;
+      const double *f21 = f11 + ng, *f12 = f11 + (size_t)kd.nP * ng, *f22 = f12 + ng;
+      const double fx1 = p1 * f11[lane] + q1 * f21[lane];
+      const double fx2 = p1 * f12[lane] + q1 * f22[lane];
+      const double v = ten2power(p2 * fx1 + q2 * fx2) * c.cols[kd.sp * nz + jk];
+      if (s == 0) s_tk[lane] = v;
+      else s_kc[lane] = v;
+    }
+    __syncthreads();
+    if (s == 0) continue;
+    for (int m = lane; m < N2; m += 64) {
+      double v = __longlong_as_double(0x7ff0000000000000LL);  // +inf padding sorts last
+      if (m < n2) v = s_tk[m / ng] + s_kc[m % ng];            // tau_xy(:, j+(i-1)*ng), :828
+      s_key[m] = v;
+      s_idx[m] = m;
+    }
+    __syncthreads();
+    for (int k = 2; k <= N2; k <<= 1) {
+      for (int d = k >> 1; d > 0; d >>= 1) {
+        for (int u = lane; u < (N2 >> 1); u += 64) {
+          const int i = ((u & ~(d - 1)) << 1) | (u & (d - 1));
+          const int x = i + d;
+          const bool up = (i & k) == 0;
+          const double ka = s_key[i], kb = s_key[x];
+          const int ia = s_idx[i], ib = s_idx[x];
+          const bool gtr = (ka > kb) || (ka == kb && ia > ib);
+          if (gtr == up) { s_key[i] = kb; s_key[x] = ka; s_idx[i] = ib; s_idx[x] = ia; }
+        }
+        __syncthreads();
+      }
+    }
+    if (lane == 0) {
+      double cum = 0.0;
+      s_cum[0] = 0.0;
+      for (int m = 0; m < n2; m++) { cum = cum + p.wxy[s_idx[m]]; s_cum[m + 1] = cum; }
+    }
+    __syncthreads();
+    if (lane < ng) {
+      const double b0 = p.wbin_e[lane], b1 = p.wbin_e[lane + 1];
+      int lo = 0, hi = n2;  // first old bin whose upper edge is above b0
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cum[mid + 1] <= b0) lo = mid + 1; else hi = mid; }
+      double acc = 0.0;
+      for (int m = lo; m < n2; m++) {
+        const double e0 = s_cum[m], e1 = s_cum[m + 1];
+        if (e0 >= b1) break;
+        const double a = e0 > b0 ? e0 : b0, b = e1 < b1 ? e1 : b1;
+        if (b > a) acc = acc + (b - a) * s_key[m];
+      }
+      s_out[lane] = acc / (b1 - b0);
+    }
+    __syncthreads();
+    if (lane < ng) s_tk[lane] = s_out[lane];
+    __syncthreads();
+  }
+
+  // ---- totals (:856-886)
+  if (lane < ng) {
+    const double tau = tausg + taua + taup + s_tk[lane] + tauc;
+    double w0;
+    if (tau <= TAU_MIN) w0 = 0.0;
+    else w0 = fmin(MAX_W0, (tausg + tausp + tausc) / tau);
+    const size_t o = ((size_t)l * ng + lane) * nz + n;
+    p.tau[o] = tau;
+    p.w0[o] = w0;
+    s_out[lane] = tau;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double tb = 0.0;
+    for (int g = 0; g < ng; g++) tb = tb + s_out[g] * p.wbin[g];
+    p.tau_band[(size_t)l * nz + n] = tb;
+    p.g[(size_t)l * nz + n] = gt;
+  }
+}
+
 bool launch_opacity(const OpacityParams &p, hipStream_t s) {
-  if (p.ng != 8) return false;
   const long total = (long)p.nbins * p.nz;
+  if (p.ng != 8) {
+    if (p.ng < 1 || p.ng > OPG_MAX_NG) return false;
+    if (total <= 0) return true;
+    int N2 = 2;
+    while (N2 < p.ng * p.ng) N2 <<= 1;
+    const size_t lds = sizeof(double) * ((size_t)N2 + p.ng * p.ng + 1 + 3 * p.ng) + sizeof(int) * (size_t)N2;
+    hipLaunchKernelGGL(k_opacity_generic, dim3((unsigned)total), dim3(64), lds, s, p, N2);
+    return true;
+  }
   if (total <= 0) return true;
   const int grid = (int)((total + OP_THREADS - 1) / OP_THREADS);
   if (p.multi_edge) hipLaunchKernelGGL(k_opacity8<true>, dim3(grid), dim3(OP_THREADS), 0, s, p);
@@ -1124,7 +1284,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
   constexpr bool solar = SOLAR;
   const int ll = (solar ? p.sol_lo : p.ir_lo) + bin_local;
   const int l = (solar ? p.sol_start : p.ir_start) + ll;  // opacity bin (radiate.f90:57)
-  const int c_raw = blockIdx.y * TSW_COLS + wave;
+  const int c_raw = p.col_base + blockIdx.y * TSW_COLS + wave;
   const bool col_on = c_raw < ng;
   const int c = col_on ? c_raw : ng - 1;
   const double wcol = col_on ? p.wbin[c] : 0.0;  // g-point weight (radiate.f90:122-126)
@@ -1393,7 +1553,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
   }
   __syncthreads();
   // ---- sum over the block's g-points, unit factors (radiate.f90:167-180), reversal (:140-154)
-  const bool split = gridDim.y > 1;
+  const bool split = p.accumulate != 0;
   double scale = 1.0;
   if (solar) scale = p.photons_sol[ll] * p.photon_scale_factor;  // clima_radtran.f90:302
   for (int n = threadIdx.x; n < nl; n += blockDim.x) {
@@ -1418,7 +1578,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
       else { p.ir_fup_a[o] = fu; p.ir_fdn_a[o] = fd; }
     }
   }
-  if (blockIdx.y == 0) {
+  if (blockIdx.y == 0 && p.col_base == 0) {
     double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
     for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = p.tau_band[(size_t)l * nz + (nz - 1 - i)];
   }
@@ -1457,7 +1617,6 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   const int lmax = (p.nz + 63) / 64;
   if (lmax > 8) return false;
   const int groups = (p.ng + TSW_COLS - 1) / TSW_COLS;
-  if (groups > 2) return false;  // keep at most two partial sums per output (order-independent)
   const size_t lds = sizeof(double) * 3 * TSW_COLS * ((size_t)p.nz + 1);
   if (lds_bytes) *lds_bytes = lds;
   if (lds > 160 * 1024) return false;
@@ -1470,9 +1629,18 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
     (void)hipFuncSetAttribute((const void *)k_twostream_w<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  const dim3 g(grid, groups), blk(64 * TSW_COLS);
-  if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4>), g, blk, lds, s, p);
-  else hipLaunchKernelGGL((k_twostream_w<8>), g, blk, lds, s, p);
+  // Up to two g-point groups go in one launch: two partial sums added into a zeroed output
+  // are order-independent.  More groups (ng > 8) run as one launch per group on the same
+  // stream, each adding a single addend, so results stay bitwise reproducible.
+  const dim3 blk(64 * TSW_COLS);
+  const int per_launch = groups <= 2 ? groups : 1;
+  for (int g0 = 0; g0 < groups; g0 += per_launch) {
+    p.col_base = g0 * TSW_COLS;
+    p.accumulate = groups > 1 ? 1 : 0;
+    const dim3 g(grid, per_launch);
+    if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4>), g, blk, lds, s, p);
+    else hipLaunchKernelGGL((k_twostream_w<8>), g, blk, lds, s, p);
+  }
   return true;
 }
 

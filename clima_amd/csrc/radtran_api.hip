@@ -375,7 +375,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
       const char *mode = getenv("CLIMA_HIP_TS_MODE");
       const bool wave_mode = !(mode && std::strcmp(mode, "block") == 0) && (nz + 63) / 64 <= 8;
       pre_zeroed = false;
-      if (wave_mode && twostream_w_groups(r->ng) == 2) {
+      if (wave_mode && twostream_w_groups(r->ng) >= 2) {
         const size_t nl = (size_t)nz + 1;
         int n = 0;
         if (r->ir_n > 0) {
@@ -416,7 +416,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     {
       KernelTimer t(r, 1);
       if (!launch_opacity(op, r->stream))
-        throw HipFail{"this build supports k-distributions with 8 g-points only (got " + std::to_string(r->ng) + ")"};
+        throw HipFail{"k-distributions with " + std::to_string(r->ng) + " g-points are not supported (1..32)"};
       t.stop();
     }
     r->opr_valid = true;

@@ -125,6 +125,7 @@ struct TwoStreamParams {
   int nz, ng;
   int debug_skip;                          // developer ablation mask (0 in production)
   int ncols, nchunks, nc_shift;            // g-point columns per block, chunks per column, log2(ncols) or -1 (launcher)
+  int col_base, accumulate;                // wave kernel: first g-point of this launch; add into the outputs (launcher)
   // task list: blocks [0, n_sol) are solar bins sol_lo.., blocks [n_sol, n_sol+n_ir) IR bins
   int n_sol, sol_lo, n_ir, ir_lo;          // channel-local first bin of this launch
   int sol_start, ir_start;                 // channel -> opacity-bin offset (RTChannel%ind_start)
@@ -165,7 +166,7 @@ struct IntegrateParams {
 
 // launchers (kernels.hip)
 void launch_prep(const PrepParams &p, hipStream_t s);
-// returns false when ng is unsupported by the compiled kernels
+// returns false when ng is unsupported by the compiled kernels (ng = 8 tuned; 1..32 generic)
 bool launch_opacity(const OpacityParams &p, hipStream_t s);
 bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
 bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed);

@@ -154,6 +154,16 @@ def test_uneven_g_weights_multi_edge_rebin(O):
     _compare(r, o, S.modern_earth_column(33))
 
 
+@pytest.mark.parametrize("ng,sorted_k", [(4, True), (6, True), (12, False), (16, True), (32, True)])
+def test_other_g_point_counts_generic_kernel(O, ng, sorted_k):
+    # `new_num_k_bins` need not be 8: the generic resort-rebin kernel (wave per (bin, layer),
+    # bitonic sort on (value, index) in LDS) and the per-group two-stream launches
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=12, ng=ng, sorted_k=sorted_k, seed=5 + ng)
+    r, o = _pair(O, tb, 22, 2, 0.25)
+    _compare(r, o, S.doubled_column(S.modern_earth_column(11)))
+
+
 def test_ties_and_zero_columns(O, small_tables):
     # a species with zero abundance gives 8-fold ties in every resort
     from clima_amd import synthetic as S
