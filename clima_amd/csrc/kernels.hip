@@ -190,9 +190,11 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
   __syncthreads();
   const double *axis = in_lds ? s_axis : sl.axis;
   for (int j = threadIdx.x; j < nz; j += blockDim.x) {
-    const int js = reuse_source(p, j);
+    // custom optical properties are evaluated for every layer itself (types.f90:564-569)
+    const int js = sl.source < 0 ? j : reuse_source(p, j);
     double x;
-    if (sl.source == 0) x = log10(c.P[js]);
+    if (sl.source < 0) x = log10(c.P[js] * 1.0e6);  // log10P_cgs, types.f90:606
+    else if (sl.source == 0) x = log10(c.P[js]);
     else if (sl.source == 1) x = c.T[js];
     else x = c.radii[(sl.source - 2) * nz + js];
     if (sl.flag_clamp && (x < sl.lo || x > sl.hi)) atomicMax(c.err_flag, p.call_id);  // stamped, never reset
@@ -354,7 +356,7 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
   for (int q = 1; q < 8; q++) out[q] = (Ik[q] - Ik[q - 1]) * rW[q];
 }
 
-template <bool MULTI>
+template <bool MULTI, bool CUSTOM>
 __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   constexpr int NG = 8;
   __shared__ double sI[NG][OP_THREADS];  // per-lane private slots (slot-major: conflict-free)
@@ -426,8 +428,17 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
       }
     }
   }
-  // ---- custom opacity unset (:558-562, :726-730): tiny everywhere
-  const double tauc = TINY, tausc = TINY * TINY;
+  // ---- custom opacity (:540-572, :726-730); tiny everywhere when unset (:558-562)
+  double tauc = TINY, tausc = TINY * TINY, g0c = TINY;
+  if constexpr (CUSTOM) {
+    const int ix = c.ix[p.cust.slot * nz + j];
+    const double q = c.q[p.cust.slot * nz + j];
+    const size_t o = (size_t)l * p.cust.nP;
+    tauc = lerp1(p.cust.dtau + o, ix, q) * dzj;
+    const double w0c = lerp1(p.cust.w0 + o, ix, q);
+    g0c = lerp1(p.cust.g0 + o, ix, q);
+    tausc = w0c * tauc;
+  }
   // ---- particles (:680-683, :733-757)
   double tausp = 0.0, taup = 0.0;
   double tausp_1[MAX_PART], gtp[MAX_PART];
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   }
   double gt = 0.0;
   for (int i = 0; i < p.npart; i++) gt = gt + gtp[i] * tausp_1[i] / fmax(TAU_MIN, (tausp + tausg + tausc));
-  gt = gt + TINY * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
+  gt = gt + g0c * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
   gt = fmin(gt, MAX_GT);
 
   STAMP(p.stamps, 1);
@@ -578,7 +589,16 @@ __global__ __launch_bounds__(64) void k_opacity_generic(OpacityParams p, int N2)
     }
     taua = taua + sgm * c.absw[e * nz + j];
   }
-  const double tauc = TINY, tausc = TINY * TINY;
+  double tauc = TINY, tausc = TINY * TINY, g0c = TINY;
+  if (p.cust.on) {
+    const int ix = c.ix[p.cust.slot * nz + j];
+    const double q = c.q[p.cust.slot * nz + j];
+    const size_t o = (size_t)l * p.cust.nP;
+    tauc = lerp1(p.cust.dtau + o, ix, q) * dzj;
+    const double w0c = lerp1(p.cust.w0 + o, ix, q);
+    g0c = lerp1(p.cust.g0 + o, ix, q);
+    tausc = w0c * tauc;
+  }
   double tausp = 0.0, taup = 0.0;
   double tausp_1[MAX_PART], gtp[MAX_PART];
   for (int i = 0; i < p.npart; i++) {
@@ -596,7 +616,7 @@ __global__ __launch_bounds__(64) void k_opacity_generic(OpacityParams p, int N2)
   }
   double gt = 0.0;
   for (int i = 0; i < p.npart; i++) gt = gt + gtp[i] * tausp_1[i] / fmax(TAU_MIN, (tausp + tausg + tausc));
-  gt = gt + TINY * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
+  gt = gt + g0c * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
   gt = fmin(gt, MAX_GT);
 
   // ---- k-distributions and random-overlap mixing
@@ -694,8 +714,13 @@ bool launch_opacity(const OpacityParams &p, hipStream_t s) {
   }
   if (total <= 0) return true;
   const int grid = (int)((total + OP_THREADS - 1) / OP_THREADS);
-  if (p.multi_edge) hipLaunchKernelGGL(k_opacity8<true>, dim3(grid), dim3(OP_THREADS), 0, s, p);
-  else hipLaunchKernelGGL(k_opacity8<false>, dim3(grid), dim3(OP_THREADS), 0, s, p);
+  if (p.cust.on) {
+    if (p.multi_edge) hipLaunchKernelGGL((k_opacity8<true, true>), dim3(grid), dim3(OP_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((k_opacity8<false, true>), dim3(grid), dim3(OP_THREADS), 0, s, p);
+  } else {
+    if (p.multi_edge) hipLaunchKernelGGL((k_opacity8<true, false>), dim3(grid), dim3(OP_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((k_opacity8<false, false>), dim3(grid), dim3(OP_THREADS), 0, s, p);
+  }
   return true;
 }
 

@@ -15,6 +15,7 @@
 #include <set>
 #include <string>
 #include <utility>
+#include <limits>
 #include <vector>
 
 using namespace clima;
@@ -124,6 +125,11 @@ struct Radtran {
   // column + prep
   int nslots = 0;
   std::vector<SlotDev> slots;
+  // custom optical properties (types.f90:432-548): tables [nw][nP] on the device, axis log10(P cgs) ascending
+  bool cust_on = false;
+  int cust_nP = 0;
+  std::vector<double> cust_axis;
+  DevBuf<double> d_cust_axis, d_cust_dtau, d_cust_w0, d_cust_g0;
   DevBuf<double> d_col;  // [T_surface | T | P | dz | dens | pdens | radii]
   DevBuf<double> d_log10P, d_cols, d_foreign, d_q, d_absw;
   std::vector<AbsEntry> abs_entries;  // continuum terms in the reference's summation order
@@ -366,6 +372,13 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     pp.has_cont = r->has_cont; pp.LH2O = r->LH2O;
     pp.check_radii = (r->column_has_particles && !r->part.empty()) ? 1 : 0;  // types.f90:628
     for (int s = 0; s < r->nslots; s++) pp.slots[s] = r->slots[s];
+    if (r->cust_on) {  // evaluated without clamping: the end intervals extrapolate (linear_interpolation_module.F90:348-350)
+      SlotDev cs;
+      cs.axis = r->d_cust_axis.p; cs.n = r->cust_nP; cs.source = -1;
+      cs.lo = -std::numeric_limits<double>::infinity(); cs.hi = std::numeric_limits<double>::infinity();
+      cs.flag_clamp = 0;
+      pp.slots[pp.nslots++] = cs;
+    }
     pp.nabs = (int)r->abs_entries.size();
     for (int e = 0; e < pp.nabs; e++) { pp.abs_kind[e] = r->abs_entries[e].kind; pp.abs_a[e] = r->abs_entries[e].a; pp.abs_b[e] = r->abs_entries[e].b; }
     pp.col = col;
@@ -408,6 +421,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
       op.part[i] = PartDev{r->part[i]->d_w0.p, r->part[i]->d_qext.p, r->part[i]->d_gt.p, r->part[i]->p_ind, r->part[i]->nrad, r->part_slot[i]};
     op.wbin = r->d_wbin.p; op.wbin_e = r->d_wbin_e.p; op.wxy = r->d_wxy.p; op.wbin_e_pad = r->d_wbin_e_pad.p;
     op.col = col;
+    op.cust = CustomDev{r->d_cust_dtau.p, r->d_cust_w0.p, r->d_cust_g0.p, r->cust_nP, r->nslots, r->cust_on ? 1 : 0};
     op.multi_edge = (*std::max_element(r->wxy.begin(), r->wxy.end()) > *std::min_element(r->wbin.begin(), r->wbin.end())) ? 1 : 0;
 #ifdef CLIMA_STAMPS
     op.stamps = r->d_stamps.p;
@@ -669,6 +683,80 @@ void radtran_set_photons_sol(void *ptr, const int *n, const double *photons_sol,
   r->fields_dirty = true;
 }
 
+// futils v0.1.14 interp(xg, x, y, yg, ierr=) as called at types.f90:487-497: piecewise linear,
+// constant beyond both ends (linear_extrap defaults to false); nonzero when x is not ascending
+static int futils_interp(const std::vector<double> &xg, int n, const double *x, const double *y, double *yg) {
+  if (n < 1) return -1;
+  for (int i = 1; i < n; i++) if (!(x[i] > x[i - 1])) return -2;
+  for (size_t i = 0; i < xg.size(); i++) {
+    const double xv = xg[i];
+    if (xv <= x[0]) yg[i] = y[0];
+    else if (xv >= x[n - 1]) yg[i] = y[n - 1];
+    else {
+      int lo = 0, hi = n - 1;
+      while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (xv < x[mid]) hi = mid; else lo = mid; }
+      const double slope = (y[lo + 1] - y[lo]) / (x[lo + 1] - x[lo]);
+      yg[i] = y[lo] + slope * (xv - x[lo]);
+    }
+  }
+  return 0;
+}
+
+// clima/fortran/Radtran.f90:77-107 -> Radtran_set_custom_optical_properties (clima_radtran.f90:494-506)
+// -> OpticalProperties_set_custom_optical_properties (clima_radtran_types.f90:432-538)
+void radtran_set_custom_optical_properties(void *ptr, const int *dim_wv, const double *wv, const int *dim_P,
+                                           const double *P, const int *dim1_dtau_dz, const int *dim2_dtau_dz,
+                                           const double *dtau_dz, const int *dim1_w0, const int *dim2_w0,
+                                           const double *w0, const int *dim1_g0, const int *dim2_g0,
+                                           const double *g0, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  const int nwv = *dim_wv, nP = *dim_P;
+  for (int i = 0; i < nwv; i++) if (wv[i] <= 0.0) { set_err(err, "All elements of `wv` must be larger than zero"); return; }
+  for (int i = 0; i < nP; i++) if (P[i] <= 0.0) { set_err(err, "All elements of `P` must be larger than zero"); return; }
+  if (nP != *dim1_dtau_dz) { set_err(err, "`P` and `dtau_dz` have incompatible shapes"); return; }
+  if (nwv != *dim2_dtau_dz) { set_err(err, "`wv` and `dtau_dz` have incompatible shapes"); return; }
+  if (nP != *dim1_w0) { set_err(err, "`P` and `w0` have incompatible shapes"); return; }
+  if (nwv != *dim2_w0) { set_err(err, "`wv` and `w0` have incompatible shapes"); return; }
+  if (nP != *dim1_g0) { set_err(err, "`P` and `g0` have incompatible shapes"); return; }
+  if (nwv != *dim2_g0) { set_err(err, "`wv` and `g0` have incompatible shapes"); return; }
+  TRY
+  const int nw = r->nw;
+  std::vector<double> wv1(nw), row(nwv), tmp(nw);
+  for (int i = 0; i < nw; i++) wv1[i] = 0.5 * (r->wavl[i + 1] + r->wavl[i]);  // :479
+  std::vector<double> tab[3];
+  const double *src[3] = {dtau_dz, w0, g0};
+  for (auto &t : tab) t.assign((size_t)nw * nP, 0.0);
+  for (int i = 0; i < nP; i++) {
+    const int j = nP - 1 - i;  // :483
+    for (int a = 0; a < 3; a++) {
+      for (int k = 0; k < nwv; k++) row[k] = src[a][i + (size_t)k * nP];
+      if (futils_interp(wv1, nwv, wv, row.data(), tmp.data()) != 0) {
+        set_err(err, "Interpolation error in `set_custom_optical_properties`");
+        return;
+      }
+      for (int l = 0; l < nw; l++) tab[a][(size_t)l * nP + j] = tmp[l];
+    }
+  }
+  std::vector<double> lp(nP);
+  for (int i = 0; i < nP; i++) lp[nP - 1 - i] = std::log10(P[i]);  // :505-506
+  bool ok = nP >= 2;  // linear_interp_1d%initialize: two or more strictly increasing nodes
+  for (int i = 1; i < nP && ok; i++) ok = lp[i] > lp[i - 1];
+  if (!ok) { set_err(err, "Interpolation initialization error in `set_custom_optical_properties`"); return; }
+  HIPCHK(hipStreamSynchronize(r->stream));  // a previous call may still read the old tables
+  r->cust_axis = lp; r->cust_nP = nP;
+  r->d_cust_axis.upload(lp); r->d_cust_dtau.upload(tab[0]); r->d_cust_w0.upload(tab[1]); r->d_cust_g0.upload(tab[2]);
+  r->cust_on = true;
+  CATCH(err)
+}
+
+// clima/fortran/Radtran.f90:109-118
+void radtran_unset_custom_optical_properties(void *ptr) {
+  Radtran *r = as_rad(ptr);
+  if (r) r->cust_on = false;
+}
+
 void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *surface_albedo, char *err) {
   clear_err(err);
   GUARD(r, ptr, err);
@@ -739,7 +827,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
     add_slot(p->d_radii.p, p->radii, 2 + p->p_ind, true);
   }
   r->nslots = (int)r->slots.size();
-  if (r->nslots > MAX_SLOTS) throw HipFail{"too many interpolated tables for this build"};
+  if (r->nslots + 1 > MAX_SLOTS) throw HipFail{"too many interpolated tables for this build"};  // one kept for custom opacity
   r->d_wbin.upload(r->wbin); r->d_wbin_e.upload(r->wbin_e); r->d_wxy.upload(r->wxy);
   {
     std::vector<double> pad = r->wbin_e;
@@ -766,7 +854,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   HIPCHK(hipHostMalloc((void **)&r->h_col, sizeof(double) * r->col_count));
   r->d_log10P.alloc(nz); r->d_cols.alloc((size_t)nz * r->nsp); r->d_foreign.alloc(nz);
   r->d_absw.alloc((size_t)std::max<size_t>(1, r->abs_entries.size()) * nz);
-  r->d_src.alloc(nz); r->d_ix.alloc((size_t)std::max(1, r->nslots) * nz); r->d_q.alloc((size_t)std::max(1, r->nslots) * nz);
+  r->d_src.alloc(nz); r->d_ix.alloc((size_t)(r->nslots + 1) * nz); r->d_q.alloc((size_t)(r->nslots + 1) * nz);
   r->d_err.alloc(1); r->d_err.zero();
 #ifdef CLIMA_STAMPS
   r->d_stamps.alloc(64 + 2 * 8192); r->d_stamps.zero();

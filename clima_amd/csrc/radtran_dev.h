@@ -27,7 +27,7 @@ constexpr int MAX_K = 8;      // k-distribution species
 constexpr int MAX_XS = 16;    // per Xsection kind
 constexpr int MAX_PART = 4;   // particle species
 constexpr int MAX_ZEN = 16;   // zenith angles passed by value to the two-stream kernel
-constexpr int MAX_SLOTS = 2 * MAX_K + 2 * MAX_XS + 1 + MAX_PART;
+constexpr int MAX_SLOTS = 2 * MAX_K + 2 * MAX_XS + 1 + MAX_PART + 1;  // + custom optical properties axis
 
 // src/clima_const.f90:9-21
 constexpr double PLANK = 6.62607004e-34;
@@ -75,7 +75,7 @@ struct PartDev {
 struct SlotDev {
   const double *axis;
   int n;
-  int source;  // 0 = log10(P), 1 = T, 2+p = radius of particle column p
+  int source;  // 0 = log10(P), 1 = T, 2+p = radius of particle column p, -1 = log10(P*1e6) of the layer itself (custom opacity)
   double lo, hi;
   int flag_clamp;  // particles: out-of-range radius is an error (types.f90:973-976)
 };
@@ -89,6 +89,12 @@ struct ColumnDev {
   double *q;       // [nslots][nz]
   int *err_flag;   // device error word: id of the last call that clamped a particle radius
   const double *T_surface;  // device scalar
+};
+
+// custom optical properties (types.f90:432-572): per bin, linear in log10(P cgs)
+struct CustomDev {
+  const double *dtau, *w0, *g0;  // [nw][nP]
+  int nP, slot, on;
 };
 
 struct OpacityParams {
@@ -107,6 +113,7 @@ struct OpacityParams {
   double *tau, *w0, *g, *tau_band;        // opr
   long long *stamps;                      // diagnostic build only (-DCLIMA_STAMPS); null otherwise
   int multi_edge;                         // max(wxy) > min(wbin): a sorted element may span several output edges
+  CustomDev cust;
 };
 
 struct PrepParams {

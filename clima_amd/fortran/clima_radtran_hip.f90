@@ -74,6 +74,8 @@ module clima_radtran_hip
     procedure :: skin_temperature => Radtran_skin_temperature
     procedure :: equilibrium_temperature => Radtran_equilibrium_temperature
     procedure :: apply_radiation_enhancement => Radtran_apply_radiation_enhancement
+    procedure :: set_custom_optical_properties => Radtran_set_custom_optical_properties
+    procedure :: unset_custom_optical_properties => Radtran_unset_custom_optical_properties
     procedure :: destroy => Radtran_destroy
   end type
 
@@ -145,6 +147,17 @@ module clima_radtran_hip
     subroutine c_radtran_apply_radiation_enhancement(ptr, rad_enhancement) bind(c, name="radtran_apply_radiation_enhancement")
       import; type(c_ptr), value :: ptr
       real(c_double), intent(in) :: rad_enhancement
+    end subroutine
+    subroutine c_radtran_set_custom_optical_properties(ptr, dim_wv, wv, dim_P, P, dim1_t, dim2_t, dtau_dz, &
+                                                       dim1_w, dim2_w, w0, dim1_g, dim2_g, g0, err) &
+                                                       bind(c, name="radtran_set_custom_optical_properties")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim_wv, dim_P, dim1_t, dim2_t, dim1_w, dim2_w, dim1_g, dim2_g
+      real(c_double), intent(in) :: wv(*), P(*), dtau_dz(*), w0(*), g0(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_unset_custom_optical_properties(ptr) bind(c, name="radtran_unset_custom_optical_properties")
+      import; type(c_ptr), value :: ptr
     end subroutine
     subroutine c_radtran_set_bolometric_flux_wrapper(ptr, flux) bind(c, name="radtran_set_bolometric_flux_wrapper")
       import; type(c_ptr), value :: ptr
@@ -578,6 +591,26 @@ contains
     real(dp), intent(in) :: rad_enhancement
     call c_radtran_apply_radiation_enhancement(self%handle, rad_enhancement)
     call pull_results(self, .true.)
+  end subroutine
+
+  !> clima_radtran.f90:494-506
+  subroutine Radtran_set_custom_optical_properties(self, wv, P, dtau_dz, w0, g0, err)
+    class(Radtran), intent(inout) :: self
+    real(dp), intent(in) :: wv(:), P(:)
+    real(dp), intent(in) :: dtau_dz(:,:), w0(:,:), g0(:,:)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: cerr(ERR_LEN+1)
+    real(dp), allocatable :: a(:,:), b(:,:), c(:,:)
+    a = dtau_dz; b = w0; c = g0   ! contiguous copies
+    call c_radtran_set_custom_optical_properties(self%handle, size(wv), wv, size(P), P, &
+      size(a,1), size(a,2), a, size(b,1), size(b,2), b, size(c,1), size(c,2), c, cerr)
+    call take_err(cerr, err)
+  end subroutine
+
+  !> clima_radtran.f90:508-512
+  subroutine Radtran_unset_custom_optical_properties(self)
+    class(Radtran), intent(inout) :: self
+    call c_radtran_unset_custom_optical_properties(self%handle)
   end subroutine
 
   subroutine Radtran_destroy(self)

@@ -203,6 +203,24 @@ class Radtran:
     def apply_radiation_enhancement(self, rad_enhancement):
         self._L.radtran_apply_radiation_enhancement(self._ptr, _f(rad_enhancement))
 
+    def set_custom_optical_properties(self, wv, P, dtau_dz, w0, g0):
+        """Radtran%set_custom_optical_properties (src/radtran/clima_radtran.f90:494-506): `wv` nm,
+        `P` dynes/cm^2 (decreasing), `dtau_dz` 1/cm, `w0`, `g0` of shape (size(P), size(wv))."""
+        wv, P = _c(wv), _c(P)
+        arrs = [np.asfortranarray(x, dtype=np.float64) for x in (dtau_dz, w0, g0)]
+        for a in arrs:
+            if a.ndim != 2:
+                raise ClimaException("`dtau_dz`, `w0` and `g0` must be 2-D arrays")
+        args = []
+        for a in arrs:
+            args += [_i(a.shape[0]), _i(a.shape[1]), _d(a)]
+        self._L.radtran_set_custom_optical_properties(self._ptr, _i(len(wv)), _d(wv), _i(len(P)), _d(P), *args, self._err)
+        self._check()
+
+    def unset_custom_optical_properties(self):
+        """src/radtran/clima_radtran.f90:508-512"""
+        self._L.radtran_unset_custom_optical_properties(self._ptr)
+
     # ---- HBM-resident form (bench / batched callers)
     def upload_column(self, T_surface, T, P, densities, dz, pdensities=None, radii=None):
         T, P, dz, densities = _c(T), _c(P), _c(dz), _fo(densities)

@@ -99,6 +99,15 @@ void radtran_toa_fluxes_wrapper(void *ptr, const double *T_surface, const int *d
                                 char *err);
 /* Radtran%apply_radiation_enhancement (clima_radtran.f90:402-411) */
 void radtran_apply_radiation_enhancement(void *ptr, const double *rad_enhancement);
+/* clima/fortran/Radtran.f90:77-118 (same names and argument lists): custom optical properties,
+ * wv nm, P dynes/cm^2 decreasing, dtau_dz / w0 / g0 (size(P), size(wv)) column-major
+ * (src/radtran/clima_radtran_types.f90:432-548) */
+void radtran_set_custom_optical_properties(void *ptr, const int *dim_wv, const double *wv, const int *dim_P,
+                                           const double *P, const int *dim1_dtau_dz, const int *dim2_dtau_dz,
+                                           const double *dtau_dz, const int *dim1_w0, const int *dim2_w0,
+                                           const double *w0, const int *dim1_g0, const int *dim2_g0,
+                                           const double *g0, char *err);
+void radtran_unset_custom_optical_properties(void *ptr);
 
 /* ---- HBM-resident form of the same call (no PCIe inside the timed region) ----
  * upload_column copies the column into the handle's device buffers; radiate_resident

@@ -64,6 +64,9 @@ struct OrcRadtran {
   OrcXs *cia, *ray, *pxs;
   OrcPart *part;
   int has_cont, LH2O, cont_nT;
+  /* custom optical properties (types.f90:432-538): per bin l, linear in log10(P cgs) */
+  int cust_on, cust_nP;
+  double *cust_log10P, *cust_dtau, *cust_w0, *cust_g0; /* axis [nP] ascending; tables [nw][nP] */
   double *cont_temp, *cont_H2O, *cont_foreign, cont_Tmin, cont_Tmax;
   /* Ksettings, clima_radtran_types.f90:84-94 */
   double *wbin, *wbin_e, *wxy;
@@ -442,6 +445,7 @@ void orc_destroy(OrcRadtran *r) {
   for (int i = 0; i < r->npart; i++) { free(r->part[i].radii); free(r->part[i].w0); free(r->part[i].qext); free(r->part[i].gt); }
   free(r->k); free(r->part);
   free(r->cont_temp); free(r->cont_H2O); free(r->cont_foreign);
+  free(r->cust_log10P); free(r->cust_dtau); free(r->cust_w0); free(r->cust_g0);
   free(r->wavl); free(r->freq); free(r->wbin); free(r->wbin_e); free(r->wxy);
   free(r->ir.wavl); free(r->ir.freq); free(r->sol.wavl); free(r->sol.freq);
   free(r->zenith_u); free(r->zenith_w); free(r->surface_albedo); free(r->surface_emissivity); free(r->photons_sol);
@@ -449,6 +453,72 @@ void orc_destroy(OrcRadtran *r) {
   free_wrk(&r->wrk_ir); free_wrk(&r->wrk_sol); free(r->f_total);
   free(r);
 }
+
+/* futils v0.1.14 `interp(xg, x, y, yg, ierr=)` as called at clima_radtran_types.f90:487-497:
+ * piecewise-linear in x (ascending), constant beyond both ends (linear_extrap defaults to
+ * false).  Third-party, absent from /root/reference: restated from its published
+ * behaviour -- parity unpinned.  Returns nonzero when x is not strictly ascending. */
+static int futils_interp(int ng, const double *xg, int n, const double *x, const double *y, double *yg) {
+  if (n < 1) return -1;
+  for (int i = 1; i < n; i++) if (!(x[i] > x[i - 1])) return -2;
+  for (int i = 0; i < ng; i++) {
+    double xv = xg[i];
+    if (xv <= x[0]) yg[i] = y[0];
+    else if (xv >= x[n - 1]) yg[i] = y[n - 1];
+    else {
+      int lo = 0, hi = n - 1;
+      while (hi - lo > 1) { int mid = (lo + hi) / 2; if (xv < x[mid]) hi = mid; else lo = mid; }
+      double slope = (y[lo + 1] - y[lo]) / (x[lo + 1] - x[lo]);
+      yg[i] = y[lo] + slope * (xv - x[lo]);
+    }
+  }
+  return 0;
+}
+
+/* OpticalProperties_set_custom_optical_properties, clima_radtran_types.f90:432-538.
+ * dtau_dz, w0, g0 are (nP, nwv) column-major; P in dynes/cm^2, decreasing. */
+int orc_set_custom_optical_properties(OrcRadtran *r, int nwv, const double *wv, int nP, const double *P,
+                                      int d1_t, int d2_t, const double *dtau_dz, int d1_w, int d2_w,
+                                      const double *w0, int d1_g, int d2_g, const double *g0, char *err) {
+  for (int i = 0; i < nwv; i++) if (wv[i] <= 0.0) { set_err(err, "All elements of `wv` must be larger than zero"); return 1; }
+  for (int i = 0; i < nP; i++) if (P[i] <= 0.0) { set_err(err, "All elements of `P` must be larger than zero"); return 1; }
+  if (nP != d1_t) { set_err(err, "`P` and `dtau_dz` have incompatible shapes"); return 1; }
+  if (nwv != d2_t) { set_err(err, "`wv` and `dtau_dz` have incompatible shapes"); return 1; }
+  if (nP != d1_w) { set_err(err, "`P` and `w0` have incompatible shapes"); return 1; }
+  if (nwv != d2_w) { set_err(err, "`wv` and `w0` have incompatible shapes"); return 1; }
+  if (nP != d1_g) { set_err(err, "`P` and `g0` have incompatible shapes"); return 1; }
+  if (nwv != d2_g) { set_err(err, "`wv` and `g0` have incompatible shapes"); return 1; }
+  const int nw = r->nw;
+  double *wv1 = dupd(NULL, nw), *row = dupd(NULL, nwv);
+  double *t = dupd(NULL, (size_t)nw * nP), *w = dupd(NULL, (size_t)nw * nP), *g = dupd(NULL, (size_t)nw * nP);
+  double *lp = dupd(NULL, nP);
+  int bad = 0;
+  for (int i = 0; i < nw; i++) wv1[i] = 0.5 * (r->wavl[i + 1] + r->wavl[i]); /* :479 */
+  const double *src[3] = {dtau_dz, w0, g0};
+  double *dst[3] = {t, w, g};
+  double *tmp = dupd(NULL, nw);
+  for (int i = 0; i < nP && !bad; i++) {
+    int j = nP - 1 - i; /* :483 */
+    for (int a = 0; a < 3 && !bad; a++) {
+      for (int k = 0; k < nwv; k++) row[k] = src[a][i + (size_t)k * nP];
+      if (futils_interp(nw, wv1, nwv, wv, row, tmp) != 0) bad = 1;
+      for (int l = 0; l < nw; l++) dst[a][(size_t)l * nP + j] = tmp[l];
+    }
+  }
+  free(tmp); free(row); free(wv1);
+  if (bad) { free(t); free(w); free(g); free(lp); set_err(err, "Interpolation error in `set_custom_optical_properties`"); return 1; }
+  for (int i = 0; i < nP; i++) lp[nP - 1 - i] = log10(P[i]); /* :505-506 */
+  /* linear_interp_1d%initialize: at least two nodes, strictly increasing */
+  int ok = nP >= 2;
+  for (int i = 1; i < nP && ok; i++) if (!(lp[i] > lp[i - 1])) ok = 0;
+  if (!ok) { free(t); free(w); free(g); free(lp); set_err(err, "Interpolation initialization error in `set_custom_optical_properties`"); return 1; }
+  free(r->cust_log10P); free(r->cust_dtau); free(r->cust_w0); free(r->cust_g0);
+  r->cust_log10P = lp; r->cust_dtau = t; r->cust_w0 = w; r->cust_g0 = g;
+  r->cust_nP = nP; r->cust_on = 1;
+  return 0;
+}
+
+void orc_unset_custom_optical_properties(OrcRadtran *r) { r->cust_on = 0; } /* :541-548 */
 
 int orc_add_ktable(OrcRadtran *r, int sp_ind, int ng, const double *weights, int nP,
                    const double *log10P, int nT, const double *temp, const double *log10k,
@@ -786,9 +856,19 @@ static int compute_opacity(OrcRadtran *r, const double *P, const double *T,
                   foreign[k] * densities[k + (size_t)L * nz] * foreign_col[k];
       }
     }
-    /* custom opacity unset: tiny :558-562, :726-730 */
-    for (int n = 0; n < nz; n++) {
-      tauc[n] = 2.2250738585072014e-308; w0c[n] = 2.2250738585072014e-308; g0c[n] = 2.2250738585072014e-308;
+    /* custom opacity :540-572, :726-730; tiny when unset :558-562 */
+    for (int k = 0; k < nz; k++) {
+      int n = nz - 1 - k; /* reversed to TOA-first :727-729 */
+      if (!r->cust_on) {
+        tauc[n] = 2.2250738585072014e-308; w0c[n] = 2.2250738585072014e-308; g0c[n] = 2.2250738585072014e-308;
+      } else {
+        /* evaluate without clamping: dintrv extrapolates from the end intervals (:348-350) */
+        double x = log10(P[k] * 1.0e6);
+        const size_t o = (size_t)l * r->cust_nP;
+        tauc[n] = orc_interp1d(r->cust_nP, r->cust_log10P, r->cust_dtau + o, x) * dz[k];
+        w0c[n] = orc_interp1d(r->cust_nP, r->cust_log10P, r->cust_w0 + o, x);
+        g0c[n] = orc_interp1d(r->cust_nP, r->cust_log10P, r->cust_g0 + o, x);
+      }
       tausc[n] = w0c[n] * tauc[n];
     }
     /* particles :733-757 */

@@ -55,6 +55,11 @@ int orc_add_particle(OrcRadtran *r, int p_ind, int nrad, const double *radii,
 int orc_set_channels(OrcRadtran *r, int n_ir, const double *ir_wavl, int n_sol,
                      const double *sol_wavl, char *err);
 int orc_set_photons_sol(OrcRadtran *r, int n, const double *photons_sol, char *err);
+/* clima_radtran_types.f90:432-548; arrays (nP, nwv) column-major, P in dynes/cm^2 decreasing */
+int orc_set_custom_optical_properties(OrcRadtran *r, int nwv, const double *wv, int nP, const double *P,
+                                      int d1_t, int d2_t, const double *dtau_dz, int d1_w, int d2_w,
+                                      const double *w0, int d1_g, int d2_g, const double *g0, char *err);
+void orc_unset_custom_optical_properties(OrcRadtran *r);
 int orc_finalize(OrcRadtran *r, int num_zenith_angles, double surface_albedo, char *err);
 
 /* ---- public mutable fields (clima_radtran.f90:51-68) ---- */

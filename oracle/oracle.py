@@ -63,6 +63,10 @@ def lib():
         L.orc_add_particle.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_char_p]
         L.orc_set_channels.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_char_p]
         L.orc_set_photons_sol.argtypes = [C.c_void_p, C.c_int, _dp, C.c_char_p]
+        L.orc_set_custom_optical_properties.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp,
+                                                        C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_char_p]
+        L.orc_unset_custom_optical_properties.argtypes = [C.c_void_p]
+        L.orc_unset_custom_optical_properties.restype = None
         L.orc_finalize.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_char_p]
         L.orc_set_zenith.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         L.orc_get_zenith.argtypes = [C.c_void_p, _dp, _dp]
@@ -163,6 +167,21 @@ class OracleRadtran:
         if photon_scale_factor is not None: self.photon_scale_factor = photon_scale_factor
         self._L.orc_set_scalars(self._h, self.diurnal_fac, int(self.has_hard_surface), self.ir_tau_min,
                                 self.photon_scale_factor)
+
+    def set_custom_optical_properties(self, wv, P, dtau_dz, w0, g0):
+        """clima_radtran.f90:494-506.  Arrays (size(P), size(wv)); raises OracleError with the
+        reference's message."""
+        err = C.create_string_buffer(1025)
+        a = [_arr(wv), _arr(P)] + [_arr(np.asfortranarray(x, dtype=float).ravel(order="F")) for x in (dtau_dz, w0, g0)]
+        sh = [np.shape(x) for x in (dtau_dz, w0, g0)]
+        rc = self._L.orc_set_custom_optical_properties(self._h, len(a[0][0]), a[0][1], len(a[1][0]), a[1][1],
+                                                       sh[0][0], sh[0][1], a[2][1], sh[1][0], sh[1][1], a[3][1],
+                                                       sh[2][0], sh[2][1], a[4][1], err)
+        if rc != 0:
+            raise OracleError(err.value.decode())
+
+    def unset_custom_optical_properties(self):
+        self._L.orc_unset_custom_optical_properties(self._h)
 
     def set_zenith(self, u, w):
         ua, wa = _arr(u), _arr(w)

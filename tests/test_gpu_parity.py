@@ -164,6 +164,55 @@ def test_other_g_point_counts_generic_kernel(O, ng, sorted_k):
     _compare(r, o, S.doubled_column(S.modern_earth_column(11)))
 
 
+def _custom_props(nwv=7, nP=6, seed=3):
+    rng = np.random.default_rng(seed)
+    wv = np.geomspace(150.0, 4.0e5, nwv)             # nm; narrower than the grid -> constant extrapolation
+    # dynes/cm^2, decreasing; the column (1e6 ... ~0.2) reaches a little beyond both ends, so the
+    # end intervals extrapolate -- mildly, keeping w0 and g0 physical
+    P = np.geomspace(0.6e6, 0.5, nP)
+    dtau_dz = 10.0 ** (-8.0 + rng.uniform(-0.5, 0.5, (nP, nwv)))
+    w0 = 0.5 + 0.2 * rng.uniform(-1.0, 1.0, (nP, nwv))
+    g0 = 0.3 + 0.3 * rng.uniform(-1.0, 1.0, (nP, nwv))
+    return wv, P, dtau_dz, w0, g0
+
+
+@pytest.mark.parametrize("ng", [8, 4])
+def test_custom_optical_properties(O, ng):
+    # Radtran%set_custom_optical_properties (clima_radtran.f90:494-512): tuned and generic kernels
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=20, ng=ng, seed=21)
+    r, o = _pair(O, tb, 30, 2, 0.2)
+    col = S.modern_earth_column(30)
+    isr0, olr0 = _compare(r, o, col)
+    args = _custom_props()
+    r.set_custom_optical_properties(*args)
+    o.set_custom_optical_properties(*args)
+    isr1, olr1 = _compare(r, o, col)
+    assert abs(olr1 - olr0) > 1e-3 * abs(olr0)      # the custom opacity matters in this case
+    r.unset_custom_optical_properties()
+    o.unset_custom_optical_properties()
+    isr2, olr2 = _compare(r, o, col)
+    assert (isr2, olr2) == (isr0, olr0)
+
+
+def test_custom_optical_properties_errors(small_tables):
+    from clima_amd.radtran import Radtran, ClimaException
+    r = Radtran(small_tables, 10, 1, 0.2)
+    wv, P, t, w, g = _custom_props()
+    cases = [((-wv, P, t, w, g), "All elements of `wv` must be larger than zero"),
+             ((wv, -P, t, w, g), "All elements of `P` must be larger than zero"),
+             ((wv, P[:-1], t, w, g), "`P` and `dtau_dz` have incompatible shapes"),
+             ((wv[:-1], P, t, w, g), "`wv` and `dtau_dz` have incompatible shapes"),
+             ((wv, P, t, w[:-1], g), "`P` and `w0` have incompatible shapes"),
+             ((wv, P, t, w, g[:, :-1]), "`wv` and `g0` have incompatible shapes"),
+             ((wv[::-1].copy(), P, t, w, g), "Interpolation error in `set_custom_optical_properties`"),
+             ((wv, P[::-1].copy(), t, w, g), "Interpolation initialization error in `set_custom_optical_properties`")]
+    for a, msg in cases:
+        with pytest.raises(ClimaException) as e:
+            r.set_custom_optical_properties(*a)
+        assert str(e.value) == msg
+
+
 def test_ties_and_zero_columns(O, small_tables):
     # a species with zero abundance gives 8-fold ties in every resort
     from clima_amd import synthetic as S

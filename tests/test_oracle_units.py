@@ -92,3 +92,37 @@ def test_oracle_error_texts(O, small_tables):
     bad = col["radii"] * 1e6                                          # outside the Mie grid: ierr (:973-976)
     with pytest.raises(O.OracleError, match="Opacity computation failed in one or more wavelength bins."):
         r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"], col["pdensities"], bad)
+
+
+def test_custom_optical_properties_oracle(O):
+    """clima_radtran_types.f90:432-572: interpolation onto the bins, reversal in P, evaluation
+    with extrapolation, and the reference's error strings."""
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=16, seed=4)
+    o = O.OracleRadtran(tb, 12, 1, 0.2)
+    col = S.modern_earth_column(12)
+    base = o.TOA_fluxes(*col.args())
+    tau0 = o.opr()[0].copy()
+    wv = np.array([200.0, 1.0e3, 1.0e5])
+    P = np.array([1.0e6, 1.0e4, 1.0e2])
+    k = 3.0e-8
+    o.set_custom_optical_properties(wv, P, np.full((3, 3), k), np.full((3, 3), 0.5), np.full((3, 3), 0.3))
+    assert o.TOA_fluxes(*col.args()) != base
+    tau1 = o.opr()[0]
+    dz = np.asarray(col.args()[4])
+    # grey custom opacity: every bin and g-point gains k*dz (tau is (nz, ng, nw), TOA-first)
+    np.testing.assert_allclose(tau1, tau0 + (k * dz)[::-1][:, None, None], rtol=1e-13)
+    # a table that varies with P only: linear in log10(P cgs), extrapolated beyond the ends
+    prof = np.array([1.0e-8, 3.0e-8, 9.0e-8])[:, None] * np.ones((1, 3))
+    o.set_custom_optical_properties(wv, P, prof, np.zeros((3, 3)), np.zeros((3, 3)))
+    o.TOA_fluxes(*col.args())
+    x = np.log10(np.asarray(col.args()[2]) * 1.0e6)
+    lp, f = np.log10(P)[::-1], prof[::-1, 0]
+    expect = np.array([O.interp1d(lp, f, xi) for xi in x]) * dz
+    np.testing.assert_allclose(o.opr()[0], tau0 + expect[::-1][:, None, None], rtol=1e-13)
+    o.unset_custom_optical_properties()
+    assert o.TOA_fluxes(*col.args()) == base
+    with pytest.raises(O.OracleError, match="`P` and `w0` have incompatible shapes"):
+        o.set_custom_optical_properties(wv, P, np.zeros((3, 3)), np.zeros((2, 3)), np.zeros((3, 3)))
+    with pytest.raises(O.OracleError, match="Interpolation initialization error"):
+        o.set_custom_optical_properties(wv, P[::-1].copy(), np.zeros((3, 3)), np.zeros((3, 3)), np.zeros((3, 3)))
