@@ -1353,6 +1353,9 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
     Rsfc = p.has_hard_surface ? 1.0 - p.emissivity[ll] : 0.0;  // :186-190
   }
   const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64 (IR)
+  // batched shared-opacity IR launches: blockIdx.z selects the temperature column (strides 0 otherwise)
+  const double *Tcol = p.T + (size_t)blockIdx.z * p.b_T;
+  const double *Tsfc = p.T_surface + (size_t)blockIdx.z * p.b_Ts;
 
   // ---- layer by layer: optical coefficients and source terms of layer t, then the rows of
   //      the chunk's system that become complete with it, eliminated downward at once
@@ -1369,7 +1372,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 #pragma unroll
     for (int z = 0; z < NZMAX; z++) etc[z] = 1.0;
     if constexpr (!solar)
-      if (len > 0) bpl_top = planck_fcn(avg_freq, a == nz ? *p.T_surface : p.T[nz - 1 - a]);
+      if (len > 0) bpl_top = planck_fcn(avg_freq, a == nz ? *Tsfc : Tcol[nz - 1 - a]);
 #pragma unroll
     for (int t = 0; t < LMAX; t++) {
       G[t] = X[t] = cpb[t] = cmb[t] = dir[t] = diru[t] = 0.0;
@@ -1442,7 +1445,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
           const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
           G[t] = gam2 / (gam1 + lam);
           X[t] = fast_exp(-lam * tau_in);
-          const double bpl_bot = planck_fcn(avg_freq, i + 1 == nz ? *p.T_surface : p.T[nz - 2 - i]);  // radiate.f90:65-69
+          const double bpl_bot = planck_fcn(avg_freq, i + 1 == nz ? *Tsfc : Tcol[nz - 2 - i]);  // radiate.f90:65-69
           double b0n, b1n;  // :216-227
           if (tau_in <= p.ir_tau_min) {
             b0n = 0.5 * (bpl_top + bpl_bot);
@@ -1599,11 +1602,12 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
       if (split) { atomicAdd(&p.sol_fup_a[o], fu); atomicAdd(&p.sol_fdn_a[o], fd); atomicAdd(&p.sol_amean[o], am); }
       else { p.sol_fup_a[o] = fu; p.sol_fdn_a[o] = fd; p.sol_amean[o] = am; }
     } else {
-      if (split) { atomicAdd(&p.ir_fup_a[o], fu); atomicAdd(&p.ir_fdn_a[o], fd); }
-      else { p.ir_fup_a[o] = fu; p.ir_fdn_a[o] = fd; }
+      const size_t ob = o + (size_t)blockIdx.z * p.b_out;
+      if (split) { atomicAdd(&p.ir_fup_a[ob], fu); atomicAdd(&p.ir_fdn_a[ob], fd); }
+      else { p.ir_fup_a[ob] = fu; p.ir_fdn_a[ob] = fd; }
     }
   }
-  if (blockIdx.y == 0 && p.col_base == 0) {
+  if (blockIdx.y == 0 && p.col_base == 0 && p.b_out == 0) {
     double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
     for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = p.tau_band[(size_t)l * nz + (nz - 1 - i)];
   }
@@ -1662,7 +1666,7 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   for (int g0 = 0; g0 < groups; g0 += per_launch) {
     p.col_base = g0 * TSW_COLS;
     p.accumulate = groups > 1 ? 1 : 0;
-    const dim3 g(grid, per_launch);
+    const dim3 g(grid, per_launch, p.b_ncol > 0 ? p.b_ncol : 1);
     if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4>), g, blk, lds, s, p);
     else hipLaunchKernelGGL((k_twostream_w<8>), g, blk, lds, s, p);
   }
@@ -1714,6 +1718,42 @@ __global__ __launch_bounds__(1024) void k_integrate_final(IntegrateParams p) {
   if (p.f_total)
     for (int i = threadIdx.x; i < nl; i += blockDim.x)
       p.f_total[i] = (p.flux_n[3 * nl + i] - p.flux_n[2 * nl + i]) + (p.flux_n[1 * nl + i] - p.flux_n[0 * nl + i]);
+}
+
+// Batched IR form (shared opacity, ncol temperature columns): the same two deterministic
+// stages per column, then f_total with the solar level fluxes of the handle's last solar call.
+__global__ __launch_bounds__(256) void k_integrate_partial_b(BatchIntegrateParams p) {
+  const int nl = p.nz + 1;
+  const int a = blockIdx.y, col = blockIdx.z;
+  const double *src = (a == 0 ? p.fup_a : p.fdn_a) + (size_t)col * p.spec_stride;
+  const int l0 = p.ir_lo + blockIdx.x * INT_CHUNK;
+  const int l1 = min(p.ir_lo + p.ir_n, l0 + INT_CHUNK);
+  for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+    double acc = 0.0;
+    for (int l = l0; l < l1; l++) acc = acc + src[(size_t)l * nl + i] * (p.freq[l] - p.freq[l + 1]);
+    p.partial[(((size_t)col * 2 + a) * p.nchunk + blockIdx.x) * nl + i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_integrate_final_b(BatchIntegrateParams p) {
+  const int nl = p.nz + 1;
+  const int col = blockIdx.x;
+  for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+    double up = 0.0, dn = 0.0;
+    for (int k = 0; k < p.nchunk; k++) {
+      up = up + p.partial[(((size_t)col * 2 + 0) * p.nchunk + k) * nl + i];
+      dn = dn + p.partial[(((size_t)col * 2 + 1) * p.nchunk + k) * nl + i];
+    }
+    double *o = p.out + (size_t)(p.col0 + col) * 3 * nl;
+    o[i] = up;
+    o[nl + i] = dn;
+    o[2 * nl + i] = (p.flux_n[3 * nl + i] - p.flux_n[2 * nl + i]) + (dn - up);  // clima_radtran.f90:287
+  }
+}
+
+void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t s) {
+  hipLaunchKernelGGL(k_integrate_partial_b, dim3(p.nchunk, 2, ncol), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_integrate_final_b, dim3(ncol), dim3(256), 0, s, p);
 }
 
 int integrate_chunks(int nbins) { return nbins <= 0 ? 1 : (nbins + INT_CHUNK - 1) / INT_CHUNK; }

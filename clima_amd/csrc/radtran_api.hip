@@ -130,6 +130,8 @@ struct Radtran {
   int cust_nP = 0;
   std::vector<double> cust_axis;
   DevBuf<double> d_cust_axis, d_cust_dtau, d_cust_w0, d_cust_g0;
+  // batched shared-opacity IR calls (radtran_radiate_ir_batch)
+  DevBuf<double> d_bT, d_bTs, d_bup, d_bdn, d_bpartial, d_bout;
   DevBuf<double> d_col;  // [T_surface | T | P | dz | dens | pdens | radii]
   DevBuf<double> d_log10P, d_cols, d_foreign, d_q, d_absw;
   std::vector<AbsEntry> abs_entries;  // continuum terms in the reference's summation order
@@ -360,6 +362,33 @@ ColumnDev column_dev(Radtran *r) {
   return c;
 }
 
+TwoStreamParams make_twostream_params(Radtran *r, const ColumnDev &col, bool compute_solar) {
+  TwoStreamParams ts;
+  const int nz = r->nz;
+  std::memset(&ts, 0, sizeof(ts));
+  ts.nz = nz; ts.ng = r->ng;
+  if (const char *dbg = getenv("CLIMA_HIP_DEBUG_SKIP_TS")) ts.debug_skip = atoi(dbg);
+  if (const char *nc = getenv("CLIMA_HIP_TS_NCOLS")) ts.ncols = atoi(nc);
+  ts.n_sol = compute_solar ? r->sol_n : 0; ts.sol_lo = r->sol_lo;
+  ts.n_ir = r->ir_n; ts.ir_lo = r->ir_lo;
+  ts.sol_start = r->sol.ind_start; ts.ir_start = r->ir.ind_start;
+  ts.tau = r->d_tau.p; ts.w0 = r->d_w0.p; ts.g = r->d_g.p; ts.tau_band = r->d_tau_band.p;
+  ts.wbin = r->d_wbin.p; ts.freq = r->d_freq.p;
+  ts.T = col.T; ts.T_surface = col.T_surface;
+  ts.emissivity = r->d_emis.p; ts.has_hard_surface = r->has_hard_surface ? 1 : 0; ts.ir_tau_min = r->ir_tau_min;
+  ts.nzen = (int)r->zenith_u.size(); ts.zen_u = r->d_zen_u.p; ts.zen_w = r->d_zen_w.p; ts.zen_iu = r->d_zen_iu.p;
+  for (int z = 0; z < ts.nzen && z < MAX_ZEN; z++) {
+    ts.zen_u_v[z] = r->zenith_u[z]; ts.zen_w_v[z] = r->zenith_w[z]; ts.zen_iu_v[z] = 1.0 / r->zenith_u[z];
+  }
+  ts.albedo = r->d_albedo.p; ts.photons_sol = r->d_photons.p;
+  ts.photon_scale_factor = r->photon_scale_factor; ts.diurnal_fac = r->diurnal_fac;
+  ts.am_f1 = r->d_am_f1.p; ts.am_f2 = r->d_am_f2.p; ts.am_dw = r->d_am_dw.p;
+  ts.ir_fup_a = r->wrk_ir.fup_a.p; ts.ir_fdn_a = r->wrk_ir.fdn_a.p; ts.ir_tau_band = r->wrk_ir.tau_band.p;
+  ts.sol_fup_a = r->wrk_sol.fup_a.p; ts.sol_fdn_a = r->wrk_sol.fdn_a.p; ts.sol_amean = r->wrk_sol.amean.p;
+  ts.sol_tau_band = r->wrk_sol.tau_band.p;
+  return ts;
+}
+
 void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   upload_fields(r);
   const int nz = r->nz;
@@ -436,28 +465,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     r->opr_valid = true;
   }
 
-  TwoStreamParams ts;
-  std::memset(&ts, 0, sizeof(ts));
-  ts.nz = nz; ts.ng = r->ng;
-  if (const char *dbg = getenv("CLIMA_HIP_DEBUG_SKIP_TS")) ts.debug_skip = atoi(dbg);
-  if (const char *nc = getenv("CLIMA_HIP_TS_NCOLS")) ts.ncols = atoi(nc);
-  ts.n_sol = compute_solar ? r->sol_n : 0; ts.sol_lo = r->sol_lo;
-  ts.n_ir = r->ir_n; ts.ir_lo = r->ir_lo;
-  ts.sol_start = r->sol.ind_start; ts.ir_start = r->ir.ind_start;
-  ts.tau = r->d_tau.p; ts.w0 = r->d_w0.p; ts.g = r->d_g.p; ts.tau_band = r->d_tau_band.p;
-  ts.wbin = r->d_wbin.p; ts.freq = r->d_freq.p;
-  ts.T = col.T; ts.T_surface = col.T_surface;
-  ts.emissivity = r->d_emis.p; ts.has_hard_surface = r->has_hard_surface ? 1 : 0; ts.ir_tau_min = r->ir_tau_min;
-  ts.nzen = (int)r->zenith_u.size(); ts.zen_u = r->d_zen_u.p; ts.zen_w = r->d_zen_w.p; ts.zen_iu = r->d_zen_iu.p;
-  for (int z = 0; z < ts.nzen && z < MAX_ZEN; z++) {
-    ts.zen_u_v[z] = r->zenith_u[z]; ts.zen_w_v[z] = r->zenith_w[z]; ts.zen_iu_v[z] = 1.0 / r->zenith_u[z];
-  }
-  ts.albedo = r->d_albedo.p; ts.photons_sol = r->d_photons.p;
-  ts.photon_scale_factor = r->photon_scale_factor; ts.diurnal_fac = r->diurnal_fac;
-  ts.am_f1 = r->d_am_f1.p; ts.am_f2 = r->d_am_f2.p; ts.am_dw = r->d_am_dw.p;
-  ts.ir_fup_a = r->wrk_ir.fup_a.p; ts.ir_fdn_a = r->wrk_ir.fdn_a.p; ts.ir_tau_band = r->wrk_ir.tau_band.p;
-  ts.sol_fup_a = r->wrk_sol.fup_a.p; ts.sol_fdn_a = r->wrk_sol.fdn_a.p; ts.sol_amean = r->wrk_sol.amean.p;
-  ts.sol_tau_band = r->wrk_sol.tau_band.p;
+  TwoStreamParams ts = make_twostream_params(r, col, compute_solar);
   {
     KernelTimer t(r, 2);
     // default: wave-per-column kernel; CLIMA_HIP_TS_MODE=block selects the workgroup-per-bin form
@@ -905,6 +913,64 @@ void radtran_radiate_resident(void *ptr, const int *compute_solar, const int *co
   if (!r->column_loaded) { set_err(err, "no column has been uploaded"); return; }
   TRY
   enqueue_radiate(r, *compute_solar != 0, *compute_opacity != 0);
+  CATCH(err)
+}
+
+// Batched form of the RCE Jacobian's radiative calls (src/adiabat/clima_adiabat_solve.f90:798-812:
+// one `radiate(..., compute_solar=.false., compute_opacity=.false.)` per perturbed temperature
+// profile).  Column c gets what that call would leave in wrk_ir%fup_n, wrk_ir%fdn_n and f_total
+// (clima_radtran.f90:262-289: IR with the resident opr, solar terms of the last solar call).
+void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
+                              const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
+                              double *f_total, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  if (*dim1_T != r->nz || *dim2_T != *ncol || *ncol < 1) { set_err(err, "\"T\" has the wrong input dimension."); return; }
+  if (!r->opr_valid) { set_err(err, "radiate_ir_batch needs opacities: call radiate with compute_opacity first"); return; }
+  if (r->shard_world != 1) { set_err(err, "radiate_ir_batch is not available on a bin-sharded handle"); return; }
+  TRY
+  upload_fields(r);
+  const int nz = r->nz, nl = nz + 1, n = *ncol, nw_ir = r->ir.nw;
+  const int CH = std::min(n, 64);  // columns per launch: bounds the per-column spectra held in HBM
+  const int nchunk = integrate_chunks(r->ir_n);
+  const size_t spec = (size_t)nw_ir * nl;
+  auto ensure = [](DevBuf<double> &b, size_t count) { if (b.n < count) b.alloc(count); };  // grow-only
+  ensure(r->d_bT, (size_t)n * nz); ensure(r->d_bTs, n); ensure(r->d_bout, (size_t)n * 3 * nl);
+  ensure(r->d_bup, spec * CH); ensure(r->d_bdn, spec * CH); ensure(r->d_bpartial, (size_t)CH * 2 * nchunk * nl);
+  HIPCHK(hipMemcpyAsync(r->d_bT.p, T, sizeof(double) * (size_t)n * nz, hipMemcpyHostToDevice, r->stream));
+  HIPCHK(hipMemcpyAsync(r->d_bTs.p, T_surface, sizeof(double) * n, hipMemcpyHostToDevice, r->stream));
+  ColumnDev col = column_dev(r);
+  TwoStreamParams ts = make_twostream_params(r, col, false);
+  ts.ir_fup_a = r->d_bup.p; ts.ir_fdn_a = r->d_bdn.p;
+  ts.b_T = nz; ts.b_Ts = 1; ts.b_out = spec;
+  const bool split = twostream_w_groups(r->ng) > 1;
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const int nc = std::min(CH, n - c0);
+    if (split) {  // g-point groups add into zeroed spectra
+      HIPCHK(hipMemsetAsync(r->d_bup.p, 0, sizeof(double) * spec * nc, r->stream));
+      HIPCHK(hipMemsetAsync(r->d_bdn.p, 0, sizeof(double) * spec * nc, r->stream));
+    }
+    TwoStreamParams tb = ts;
+    tb.T = r->d_bT.p + (size_t)c0 * nz; tb.T_surface = r->d_bTs.p + c0; tb.b_ncol = nc;
+    if (!launch_twostream_w(tb, r->stream, &r->ts_lds, true))
+      throw HipFail{"radiate_ir_batch: nz = " + std::to_string(nz) + " exceeds what the wave two-stream kernel holds (512)"};
+    BatchIntegrateParams bp;
+    std::memset(&bp, 0, sizeof(bp));
+    bp.nz = nz; bp.ir_lo = r->ir_lo; bp.ir_n = r->ir_n; bp.nchunk = nchunk; bp.col0 = c0;
+    bp.fup_a = r->d_bup.p; bp.fdn_a = r->d_bdn.p; bp.spec_stride = spec;
+    bp.freq = r->ir.d_freq.p; bp.partial = r->d_bpartial.p; bp.flux_n = r->d_flux_n.p; bp.out = r->d_bout.p;
+    launch_integrate_batch(bp, nc, r->stream);
+  }
+  std::vector<double> out((size_t)n * 3 * nl);
+  HIPCHK(hipMemcpyAsync(out.data(), r->d_bout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  for (int c = 0; c < n; c++)
+    for (int i = 0; i < nl; i++) {
+      fup_n[(size_t)c * nl + i] = out[((size_t)c * 3 + 0) * nl + i];
+      fdn_n[(size_t)c * nl + i] = out[((size_t)c * 3 + 1) * nl + i];
+      f_total[(size_t)c * nl + i] = out[((size_t)c * 3 + 2) * nl + i];
+    }
   CATCH(err)
 }
 

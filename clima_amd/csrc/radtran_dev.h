@@ -133,6 +133,10 @@ struct TwoStreamParams {
   int debug_skip;                          // developer ablation mask (0 in production)
   int ncols, nchunks, nc_shift;            // g-point columns per block, chunks per column, log2(ncols) or -1 (launcher)
   int col_base, accumulate;                // wave kernel: first g-point of this launch; add into the outputs (launcher)
+  // batched shared-opacity IR launches (wave kernel): gridDim.z = b_ncol temperature columns,
+  // T + z*b_T, T_surface + z*b_Ts, IR spectra + z*b_out; all 0 for a single column
+  int b_ncol, b_T, b_Ts;
+  size_t b_out;
   // task list: blocks [0, n_sol) are solar bins sol_lo.., blocks [n_sol, n_sol+n_ir) IR bins
   int n_sol, sol_lo, n_ir, ir_lo;          // channel-local first bin of this launch
   int sol_start, ir_start;                 // channel -> opacity-bin offset (RTChannel%ind_start)
@@ -171,6 +175,16 @@ struct IntegrateParams {
   int nchunk;
 };
 
+struct BatchIntegrateParams {
+  int nz, ir_lo, ir_n, nchunk, col0;
+  const double *fup_a, *fdn_a;   // [ncol][nw_ir][nz+1]
+  size_t spec_stride;
+  const double *freq;            // IR channel freq [nw_ir+1]
+  double *partial;               // [ncol][2][nchunk][nz+1]
+  const double *flux_n;          // the handle's [4][nz+1] (solar rows of the last solar call)
+  double *out;                   // [ncol_total][3][nz+1]: fup_n, fdn_n, f_total
+};
+
 // launchers (kernels.hip)
 void launch_prep(const PrepParams &p, hipStream_t s);
 // returns false when ng is unsupported by the compiled kernels (ng = 8 tuned; 1..32 generic)
@@ -179,6 +193,7 @@ bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
 bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed);
 int twostream_w_groups(int ng);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
+void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t s);
 int integrate_chunks(int nbins);
 void launch_f_total(int nz, const double *flux_n, double *f_total, hipStream_t s);
 void launch_scale(double *a, size_t n, double f, hipStream_t s);

@@ -221,6 +221,22 @@ class Radtran:
         """src/radtran/clima_radtran.f90:508-512"""
         self._L.radtran_unset_custom_optical_properties(self._ptr)
 
+    def radiate_ir_batch(self, T_surface, T):
+        """ncol IR-only calls with the resident opacities in one go: column c is
+        `radiate(T_surface[c], T[:, c], ..., compute_solar=False, compute_opacity=False)`
+        (the RCE Jacobian's loop, src/adiabat/clima_adiabat_solve.f90:798-812).
+        Returns (fup_n, fdn_n, f_total), each (nz+1, ncol)."""
+        T = np.asfortranarray(T, dtype=np.float64)
+        Ts = _c(np.atleast_1d(T_surface))
+        if T.ndim != 2 or T.shape[0] != self.nz or T.shape[1] != len(Ts):
+            raise ClimaException('"T" has the wrong input dimension.')
+        n = T.shape[1]
+        out = [np.empty((self.nz + 1, n), order="F") for _ in range(3)]
+        self._L.radtran_radiate_ir_batch(self._ptr, _i(n), _d(Ts), _i(T.shape[0]), _i(n), _d(T),
+                                         _d(out[0]), _d(out[1]), _d(out[2]), self._err)
+        self._check()
+        return tuple(out)
+
     # ---- HBM-resident form (bench / batched callers)
     def upload_column(self, T_surface, T, P, densities, dz, pdensities=None, radii=None):
         T, P, dz, densities = _c(T), _c(P), _c(dz), _fo(densities)

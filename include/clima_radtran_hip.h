@@ -132,6 +132,15 @@ void radtran_bin_shard_get(void *ptr, int *op_lo, int *op_n, int *ir_lo, int *ir
                            int *sol_n);
 /* after an external all-reduce of the flux buffer: recompute f_total on the device */
 void radtran_finish_reduced(void *ptr, char *err);
+/* Batched shared-opacity IR calls: what the RCE Jacobian does one call at a time
+ * (src/adiabat/clima_adiabat_solve.f90:798-812 -> clima_radtran.f90:221-318 with
+ * compute_solar = compute_opacity = .false.).  T is (nz, ncol) column-major, T_surface (ncol);
+ * column c receives that call's wrk_ir%fup_n, wrk_ir%fdn_n and f_total in (nz+1, ncol) arrays.
+ * Uses the opacities of the last compute_opacity call and the solar fluxes of the last solar
+ * call; the handle's own wrk_ir / f_total are left untouched. */
+void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
+                              const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
+                              double *f_total, char *err);
 /* HIP stream the handle launches on (for callers that order other work against it) */
 void radtran_stream_get(void *ptr, void **stream);
 /* per-kernel device time (HIP events on the handle's stream).  enable = 1 records events

@@ -278,6 +278,45 @@ def test_state_carried_between_calls(O, small_tables):
     _compare(r, o, warm)
 
 
+@pytest.mark.parametrize("nz,ncol", [(50, 7), (30, 70)])
+def test_batched_shared_opacity_ir_calls(O, small_tables, nz, ncol):
+    # the RCE Jacobian's loop (clima_adiabat_solve.f90:798-812) in one call: every column equals
+    # radiate(..., compute_solar=False, compute_opacity=False) on the same resident opacities
+    from clima_amd import synthetic as S
+    col = S.modern_earth_column(nz)
+    r, o = _pair(O, small_tables, nz, 2, 0.3)
+    _compare(r, o, col)
+    rng = np.random.default_rng(9)
+    T = np.repeat(np.asarray(col["T"])[:, None], ncol, axis=1)
+    Ts = np.full(ncol, float(col["T_surface"]))
+    for c in range(ncol):           # one perturbed level per column, as the Jacobian does
+        k = c % (nz + 1)
+        dT = 1.0e-2 * (1.0 + rng.random()) * (Ts[c] if k == 0 else T[k - 1, c])
+        if k == 0:
+            Ts[c] += dT
+        else:
+            T[k - 1, c] += dT
+    base_up = np.array(r.wrk_ir.fup_n)
+    fup, fdn, ftot = r.radiate_ir_batch(Ts, T)
+    assert fup.shape == (nz + 1, ncol)
+    np.testing.assert_array_equal(np.array(r.wrk_ir.fup_n), base_up)   # the handle's results stay
+    for c in range(ncol):
+        w = S.Column(col)
+        w["T"] = T[:, c].copy()
+        w["T_surface"] = Ts[c]
+        o.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+        assert _scaled(fup[:, c], o.wrk_ir.fup_n) <= TOL_LEVEL
+        assert _scaled(fdn[:, c], o.wrk_ir.fdn_n) <= TOL_LEVEL
+        assert _scaled(ftot[:, c], o.f_total) <= TOL_LEVEL
+    # and it is the same arithmetic as the one-at-a-time path
+    w = S.Column(col)
+    w["T"] = T[:, 3].copy()
+    w["T_surface"] = Ts[3]
+    r.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+    np.testing.assert_array_equal(np.array(r.wrk_ir.fup_n), fup[:, 3])
+    np.testing.assert_array_equal(np.array(r.f_total), ftot[:, 3])
+
+
 def test_radiation_enhancement_and_bolometric(O, small_tables):
     from clima_amd import synthetic as S
     col = S.modern_earth_column(50)

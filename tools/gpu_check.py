@@ -92,6 +92,36 @@ def main():
     if which in ("all", "nominal"):
         tb = S.modern_earth_tables()
         run("config 2: ModernEarth nominal", tb, S.modern_earth_column(200), 200, 8, 0.15, reps=20)
+    if which in ("jacobian",):
+        # the RCE Jacobian's radiative work: nz+1 IR-only calls on shared opacities, one at a
+        # time through the host API vs one batched call
+        tb = S.modern_earth_tables()
+        nz = 200
+        col = S.modern_earth_column(nz)
+        r = Radtran(tb, nz, 8, 0.15)
+        r.TOA_fluxes(*col.args())
+        n = nz + 1
+        T = np.repeat(np.asarray(col["T"])[:, None], n, axis=1)
+        Ts = np.full(n, float(col["T_surface"]))
+        Ts[0] *= 1.01
+        for c in range(1, n):
+            T[c - 1, c] *= 1.01
+        r.radiate_ir_batch(Ts, T)
+        t0 = time.time()
+        for _ in range(3):
+            fup, fdn, ft = r.radiate_ir_batch(Ts, T)
+        tb_ = (time.time() - t0) / 3
+        a = list(col.args())
+        t0 = time.time()
+        ref = np.empty_like(ft)
+        for c in range(n):
+            a[0] = Ts[c]; a[1] = np.ascontiguousarray(T[:, c])
+            r.radiate(*a, compute_solar=False, compute_opacity=False)
+            ref[:, c] = r.f_total
+        tl = time.time() - t0
+        print("== Jacobian radiative work, %d IR-only calls on shared opacities (nz %d)" % (n, nz))
+        print("  one at a time %.2f ms (%.1f us/call)   batched %.2f ms (%.1f us/column)   speedup %.1fx   max |diff| f_total %.2e"
+              % (tl * 1e3, tl / n * 1e6, tb_ * 1e3, tb_ / n * 1e6, tl / tb_, float(np.max(np.abs(ref - ft)))))
     if which in ("all", "mars"):
         tb = S.early_mars_tables()
         run("config 3: EarlyMars", tb, S.early_mars_column(200), 200, 4, 0.2, reps=20, photon_scale_factor=0.4286)
