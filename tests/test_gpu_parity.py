@@ -317,6 +317,17 @@ def test_batched_shared_opacity_ir_calls(O, small_tables, nz, ncol):
     np.testing.assert_array_equal(np.array(r.f_total), ftot[:, 3])
 
 
+def test_adiabat_style_doubled_radiative_grid(O, small_tables):
+    # AdiabatClimate's RT grid (clima_adiabat.f90:728-771): nz_r = 2*nz + 2 with ghost layers;
+    # every pair is a pair_reuse pair (clima_radtran_types.f90:621-632)
+    from clima_amd import synthetic as S
+    from clima_amd.atmosphere import copy_atm_to_radiative_grid
+    col = S.Column(copy_atm_to_radiative_grid(S.modern_earth_column(24)))
+    assert len(col["T"]) == 50
+    r, o = _pair(O, small_tables, 50, 4, 0.2)
+    _compare(r, o, col)
+
+
 def test_radiation_enhancement_and_bolometric(O, small_tables):
     from clima_amd import synthetic as S
     col = S.modern_earth_column(50)
