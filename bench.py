@@ -31,6 +31,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 KERNELS = ["prep", "opacity", "twostream", "integrate"]
+# HBM bytes of one k_opacity8 launch on this exact workload from the PMC passes committed under
+# profiles/ (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; bench.py cannot collect counters itself)
+PMC_TRAFFIC_BYTES = (1.652e4 + 4.684e4) * 1024.0
+PMC_TRAFFIC_SOURCE = "profiles/r01b_pmc_summary.md: k_opacity8 FETCH_SIZE 1.652e4 KiB + WRITE_SIZE 4.684e4 KiB per launch"
 
 
 def main():
@@ -42,6 +46,12 @@ def main():
     ap.add_argument("--nzen", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: anything libraries print there (RCCL's version
+    # banner at communicator creation, for one) is routed to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -56,8 +66,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Radtran hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # CLIMA_BENCH_FORCE_DIST=1 runs the N>1 step (shard -> RCCL all-reduce -> finish) with one
+    # rank, to rehearse that code path on a one-GPU box
+    dist_on = world > 1 or os.environ.get("CLIMA_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -68,21 +82,31 @@ def main():
     tables = S.modern_earth_tables()
     col = S.modern_earth_column(nz)
     rad = Radtran(tables, nz, nzen, 0.15)  # tests/test_radtran.f90:35-38
-    if world > 1:
+    if dist_on:
         rad.set_bin_shard(rank, world)
     rad.upload_column(*col.args())
-    flux = rad.flux_tensor() if world > 1 else None
+    flux = rad.flux_tensor() if dist_on else None
+    # The all-reduce is ordered against the library's kernels on the device: the library's HIP
+    # stream is made torch's current stream for the collective, so RCCL's stream waits for the
+    # partial fluxes and the library stream waits for the reduced ones -- no host round trip
+    # inside a step.  CLIMA_BENCH_HOST_SYNC=1 selects the plain host-synchronised form.
+    host_sync = os.environ.get("CLIMA_BENCH_HOST_SYNC") == "1"
+    lib_stream = torch.cuda.ExternalStream(rad.stream()) if dist_on and not host_sync else None
 
     def step():
         rad.radiate_resident()
-        if world > 1:
-            rad.synchronize()                 # library stream -> host
-            dist.all_reduce(flux)             # RCCL over xGMI: 4*(nz+1) doubles
-            torch.cuda.current_stream().synchronize()
+        if dist_on:
+            if host_sync:
+                rad.synchronize()                 # library stream -> host
+                dist.all_reduce(flux)             # RCCL over xGMI: 4*(nz+1) doubles
+                torch.cuda.current_stream().synchronize()
+            else:
+                with torch.cuda.stream(lib_stream):
+                    dist.all_reduce(flux)
             rad.finish_reduced()              # f_total from the reduced fluxes
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         rad.synchronize()
         torch.cuda.synchronize()
@@ -111,14 +135,14 @@ def main():
     kt[1] = kt_dom
     rad.profile(False)
 
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
     # ---- parity of what was just timed (rank 0 checks OLR against the oracle)
-    isr = float((flux[3 * (nz + 1) + nz] - flux[2 * (nz + 1) + nz]).item()) if world > 1 else None
-    if world > 1:
+    isr = float((flux[3 * (nz + 1) + nz] - flux[2 * (nz + 1) + nz]).item()) if dist_on else None
+    if dist_on:
         olr = -float((flux[1 * (nz + 1) + nz] - flux[0 * (nz + 1) + nz]).item())
     else:
         w_ir, w_sol = rad.wrk_ir, rad.wrk_sol
@@ -139,7 +163,9 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": b_alg / dur / 1e9 if dur > 0 else 0.0,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (b_alg / dur / 1e9) / HBM_PEAK_GBS if dur > 0 else 0.0,
-                    "traffic": None, "algorithmic_bytes": b_alg, "kernel_us": per_kernel_us,
+                    "traffic": PMC_TRAFFIC_BYTES if (dom == "opacity" and not dist_on and (nz, nzen) == (200, 8)) else None,
+                    "traffic_source": PMC_TRAFFIC_SOURCE,
+                    "algorithmic_bytes": b_alg, "kernel_us": per_kernel_us,
                     "whole_call_frac": (b_alg / (dt / args.steps) / 1e9) / HBM_PEAK_GBS}
         out = {"metric": "radiate() calls/sec", "value": value, "unit": "calls/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -153,8 +179,9 @@ def main():
                "olr_W_m2": olr / 1e3, "isr_W_m2": isr / 1e3, "roofline": roofline}
         if not args.no_cpu_baseline and world == 1:
             out.update(cpu_baseline(tables, col, nz, nzen, olr))
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist_on:
         dist.destroy_process_group()
 
 
