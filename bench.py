@@ -140,6 +140,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
+    # ---- companion figure for N > 1 (not `value`): the column-parallel form of config 4 --
+    # every rank runs whole, unsharded calls on its own column, no collective (weak scaling)
+    col_par = None
+    if dist_on:
+        rad2 = Radtran(tables, nz, nzen, 0.15)
+        rad2.upload_column(*col.args())
+        for _ in range(args.warmup):
+            rad2.radiate_resident()
+        dist.barrier(); rad2.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            rad2.radiate_resident()
+        rad2.synchronize(); dist.barrier()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        col_par = {"value": world * args.steps / float(t[0]), "unit": "calls/s", "scaling": "weak",
+                   "what": "each rank runs its own whole radiate() calls (independent columns), no collective"}
+        del rad2
+
     # ---- parity of what was just timed (rank 0 checks OLR against the oracle)
     isr = float((flux[3 * (nz + 1) + nz] - flux[2 * (nz + 1) + nz]).item()) if dist_on else None
     if dist_on:
@@ -177,6 +196,8 @@ def main():
                           "parallelism": ("bins sharded over %d GPUs + 1 all-reduce of %d f64" % (world, 4 * (nz + 1)))
                           if world > 1 else "1 GPU"},
                "olr_W_m2": olr / 1e3, "isr_W_m2": isr / 1e3, "roofline": roofline}
+        if col_par is not None:
+            out["column_parallel"] = col_par
         if not args.no_cpu_baseline and world == 1:
             out.update(cpu_baseline(tables, col, nz, nzen, olr))
         sys.stdout.flush()

@@ -25,11 +25,12 @@ XS_CIA, XS_RAYLEIGH, XS_ABSORPTION, XS_PHOTOLYSIS = 0, 1, 2, 3
 
 def build(force=False):
     """Compile liborc.so (and _ref when /root/reference is present)."""
-    lib = os.path.join(_HERE, "liborc.so")
     src = os.path.join(_HERE, "clima_oracle.c")
-    stale = (not os.path.exists(lib)) or os.path.getmtime(lib) < os.path.getmtime(src)
-    if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "liborc.so"], stdout=subprocess.DEVNULL)
+    for name in ("liborc.so", "liborc_fma.so"):
+        lib = os.path.join(_HERE, name)
+        stale = (not os.path.exists(lib)) or os.path.getmtime(lib) < os.path.getmtime(src)
+        if force or stale:
+            subprocess.check_call(["make", "-C", _HERE, name], stdout=subprocess.DEVNULL)
     ref = os.path.join(_HERE, "_ref", "libclima_twostream_ref.so")
     if os.path.isdir("/root/reference/src") and (force or not os.path.exists(ref)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -46,14 +47,15 @@ def _farr(a):
     return a, a.ctypes.data_as(_dp)
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(variant=""):
+    """variant "" = liborc.so (no FMA contraction, the oracle proper); "fma" = liborc_fma.so,
+    the same source compiled with contraction (conditioning yardstick only)."""
+    if variant not in _libs:
         build()
-        L = C.CDLL(os.path.join(_HERE, "liborc.so"))
+        L = C.CDLL(os.path.join(_HERE, "liborc%s.so" % ("_" + variant if variant else "")))
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp]
         L.orc_destroy.argtypes = [C.c_void_p]
@@ -96,8 +98,8 @@ def lib():
         L.orc_mrgrnk.argtypes = [C.c_int, _dp, _ip]
         L.orc_rebin.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, _dp]
         L.orc_gauss_legendre.argtypes = [C.c_int, _dp, _dp]
-        _lib = L
-    return _lib
+        _libs[variant] = L
+    return _libs[variant]
 
 
 class OracleError(Exception):
@@ -111,9 +113,9 @@ class _Wrk:
 class OracleRadtran:
     """CPU oracle with the shape of clima.Radtran (clima/cython/Radtran.pyx)."""
 
-    def __init__(self, tables, nz, num_zenith_angles, surface_albedo):
+    def __init__(self, tables, nz, num_zenith_angles, surface_albedo, variant=""):
         """tables: clima_amd.synthetic.TableSet-like object (duck-typed)."""
-        L = lib()
+        L = lib(variant)
         self._L = L
         t = tables
         self.nz, self.nsp, self.np_ = nz, t.nsp, t.np_

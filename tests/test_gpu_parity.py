@@ -42,19 +42,22 @@ def _pair(O, tables, nz, nzen, albedo, **scalars):
     return r, o
 
 
-def _compare(r, o, col, **kw):
+def _compare(r, o, col, flux_tol_scale=1.0, **kw):
+    """`flux_tol_scale` loosens the flux tolerances for deliberately ill-conditioned settings
+    (see test_gpu_fuzz.py); the opacity tolerances never move."""
+    f = flux_tol_scale
     isr, olr = r.TOA_fluxes(*col.args(), **kw)
     isr_o, olr_o = o.TOA_fluxes(*col.args(), **kw)
-    assert abs(olr - olr_o) <= RTOL_TOA * abs(olr_o)
-    assert abs(isr - isr_o) <= RTOL_TOA * max(abs(isr_o), 1e-300)
+    assert abs(olr - olr_o) <= f * RTOL_TOA * abs(olr_o)
+    assert abs(isr - isr_o) <= f * RTOL_TOA * max(abs(isr_o), 1e-300)
     for wg, wo in ((r.wrk_ir, o.wrk_ir), (r.wrk_sol, o.wrk_sol)):
-        assert _scaled(wg.fup_n, wo.fup_n) <= TOL_LEVEL
-        assert _scaled(wg.fdn_n, wo.fdn_n) <= TOL_LEVEL
-        assert _scaled(wg.fup_a, wo.fup_a) <= TOL_SPEC
-        assert _scaled(wg.fdn_a, wo.fdn_a) <= TOL_SPEC
-        assert _scaled(wg.amean, wo.amean) <= TOL_SPEC
+        assert _scaled(wg.fup_n, wo.fup_n) <= f * TOL_LEVEL
+        assert _scaled(wg.fdn_n, wo.fdn_n) <= f * TOL_LEVEL
+        assert _scaled(wg.fup_a, wo.fup_a) <= f * TOL_SPEC
+        assert _scaled(wg.fdn_a, wo.fdn_a) <= f * TOL_SPEC
+        assert _scaled(wg.amean, wo.amean) <= f * TOL_SPEC
         assert _rel(wg.tau_band, wo.tau_band) <= RTOL_OPR
-    assert _scaled(r.f_total, o.f_total) <= TOL_LEVEL
+    assert _scaled(r.f_total, o.f_total) <= f * TOL_LEVEL
     for a, b in zip(r.opr(), o.opr()):
         assert _rel(a, b) <= RTOL_OPR
     return isr, olr
