@@ -250,6 +250,19 @@ def test_config5_500_layers(O):
     _compare(r, o, S.modern_earth_column(500))
 
 
+def test_more_than_512_layers_falls_back_to_lds_kernel(O):
+    # beyond 8 layers per lane the wave kernel declines and the workgroup-per-bin kernel runs;
+    # beyond what one 160 KiB LDS image holds the library reports it (no silent truncation)
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran, ClimaException
+    tb = S.modern_earth_tables(nw=8, seed=56)
+    r, o = _pair(O, tb, 640, 2, 0.15)
+    _compare(r, o, S.modern_earth_column(640))
+    big = Radtran(tb, 5000, 1, 0.15)
+    with pytest.raises(ClimaException, match="exceeds what the two-stream kernels can stage"):
+        big.radiate(*S.modern_earth_column(5000).args())
+
+
 def test_config4_perturbed_columns(O, small_tables):
     # BASELINE.json configs[3]: perturbed ModernEarth columns (T-P and mixing-ratio sweep),
     # here a handful of them through one handle, one after the other
