@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 KERNELS = ["prep", "opacity", "twostream", "integrate"]
 # HBM bytes of one k_opacity8 launch on this exact workload from the PMC passes committed under
 # profiles/ (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; bench.py cannot collect counters itself)
-PMC_TRAFFIC_BYTES = (1.652e4 + 4.684e4) * 1024.0
-PMC_TRAFFIC_SOURCE = "profiles/r01b_pmc_summary.md: k_opacity8 FETCH_SIZE 1.652e4 KiB + WRITE_SIZE 4.684e4 KiB per launch"
+PMC_TRAFFIC_BYTES = (1.640e4 + 4.681e4) * 1024.0
+PMC_TRAFFIC_SOURCE = "profiles/r01d_pmc_summary.md: k_opacity8 FETCH_SIZE 1.640e4 KiB + WRITE_SIZE 4.681e4 KiB per launch"
 
 
 def main():
