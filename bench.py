@@ -199,34 +199,63 @@ def main():
         if col_par is not None:
             out["column_parallel"] = col_par
         if not args.no_cpu_baseline and world == 1:
-            out.update(cpu_baseline(tables, col, nz, nzen, olr))
+            out.update(cpu_baseline(tables, col, nz, nzen, olr, rad))
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist_on:
         dist.destroy_process_group()
 
 
-def cpu_baseline(tables, col, nz, nzen, olr_gpu):
+def cpu_baseline(tables, col, nz, nzen, olr_gpu, rad=None):
     """The oracle (port of the reference algorithm, OpenMP over bins like the reference's
     `!$omp parallel do`) on this box's host cores: whole radiate() calls of the same
-    workload, bounded to ~10-30 s."""
+    workload, bounded to ~10-30 s in all.  Timed at all usable cores (the figure in `value`)
+    and at one thread (the reference's Python default, clima/__init__.py:2)."""
     from oracle import oracle as O
     O.build()
     cores = min(os.cpu_count() or 1, 16)
-    O.lib().orc_set_num_threads(cores)
     o = O.OracleRadtran(tables, nz, nzen, 0.15)
-    o.radiate(*col.args())  # warm (page-in, thread pool)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        o.radiate(*col.args())
-        n += 1
-        el = time.perf_counter() - t0
-        if el > 12.0 or n >= 40:
-            break
+
+    def timed(threads, budget, cap):
+        O.lib().orc_set_num_threads(threads)
+        o.radiate(*col.args())  # warm (page-in, thread pool)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            o.radiate(*col.args())
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= cap:
+                return n, el
+
+    n, el = timed(cores, 10.0, 40)
+    n1, el1 = timed(1, 8.0, 8)
+    O.lib().orc_set_num_threads(cores)
     _, olr_o = o.TOA_fluxes(*col.args())
-    return {"cpu_baseline": {"value": n / el, "unit": "calls/s", "cores": cores, "kind": "port",
-                             "sample": "%d whole radiate() calls of the same workload (%.1f s)" % (n, el)},
-            "olr_rel_err_vs_cpu": abs(olr_gpu - olr_o) / abs(olr_o)}
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    out = {"cpu_baseline": {"value": n / el, "unit": "calls/s", "cores": cores, "kind": "port",
+                            "sample": "%d whole radiate() calls of the same workload (%.1f s)" % (n, el),
+                            "single_thread": {"value": n1 / el1, "unit": "calls/s",
+                                              "sample": "%d calls (%.1f s)" % (n1, el1)},
+                            "cpu_model": model, "host_cpus": os.cpu_count()},
+           "olr_rel_err_vs_cpu": abs(olr_gpu - olr_o) / abs(olr_o)}
+    if rad is not None:  # SURVEY 8(d): level fluxes of both channels and the planetary albedo
+        import numpy as np
+        errs = []
+        for wg, wo in ((rad.wrk_ir, o.wrk_ir), (rad.wrk_sol, o.wrk_sol)):
+            for a, b in ((wg.fup_n, wo.fup_n), (wg.fdn_n, wo.fdn_n)):
+                a, b = np.asarray(a), np.asarray(b)
+                errs.append(float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+        alb_g = rad.wrk_sol.fup_n[nz] / rad.wrk_sol.fdn_n[nz]
+        alb_o = o.wrk_sol.fup_n[nz] / o.wrk_sol.fdn_n[nz]
+        out["max_level_flux_err_vs_cpu"] = max(errs)
+        out["albedo"] = float(alb_g)
+        out["albedo_rel_err_vs_cpu"] = float(abs(alb_g - alb_o) / abs(alb_o))
+    return out
 
 
 if __name__ == "__main__":
