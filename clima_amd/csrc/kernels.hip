@@ -1698,7 +1698,7 @@ __global__ __launch_bounds__(256) void k_integrate_partial(IntegrateParams p) {
       for (int k = 0; k < INT_CHUNK; k++) v[k] = (l0 + k < l1) ? src[(size_t)(l0 + k) * nl + i] : 0.0;
 #pragma unroll
       for (int k = 0; k < INT_CHUNK; k++)
-        if (l0 + k < l1) acc = acc + v[k] * (freq[l0 + k] - freq[l0 + k + 1]);
+        if (l0 + k < l1) acc = __builtin_fma(v[k], freq[l0 + k] - freq[l0 + k + 1], acc);
     }
     p.partial[((size_t)a * p.nchunk + blockIdx.x) * nl + i] = acc;
   }
@@ -1730,7 +1730,7 @@ __global__ __launch_bounds__(256) void k_integrate_partial_b(BatchIntegrateParam
   const int l1 = min(p.ir_lo + p.ir_n, l0 + INT_CHUNK);
   for (int i = threadIdx.x; i < nl; i += blockDim.x) {
     double acc = 0.0;
-    for (int l = l0; l < l1; l++) acc = acc + src[(size_t)l * nl + i] * (p.freq[l] - p.freq[l + 1]);
+    for (int l = l0; l < l1; l++) acc = __builtin_fma(src[(size_t)l * nl + i], p.freq[l] - p.freq[l + 1], acc);
     p.partial[(((size_t)col * 2 + a) * p.nchunk + blockIdx.x) * nl + i] = acc;
   }
 }
@@ -1758,7 +1758,66 @@ void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t
 
 int integrate_chunks(int nbins) { return nbins <= 0 ? 1 : (nbins + INT_CHUNK - 1) / INT_CHUNK; }
 
+// Both stages in one launch: a block owns INT_LV consecutive levels of all four arrays; thread
+// (level, array, chunk group) forms the chunk sums exactly as k_integrate_partial does, the chunk
+// sums meet in LDS and are added in chunk order, then f_total.  Same association as the
+// two-launch form, one launch less on the critical path of a call.
+constexpr int INT_LV = 8;
+constexpr int INT_CG = 32;  // chunk groups per array: threads = INT_LV * 4 * INT_CG = 1024
+
+__global__ __launch_bounds__(INT_LV * 4 * INT_CG) void k_integrate_one(IntegrateParams p) {
+  extern __shared__ __align__(16) double s_part[];  // [4][nchunk][INT_LV], then [4][INT_LV] totals
+  const int nl = p.nz + 1;
+  const int lv = threadIdx.x % INT_LV;
+  const int grp = threadIdx.x / INT_LV;
+  const int a = grp / INT_CG, cg = grp % INT_CG;
+  const int i = blockIdx.x * INT_LV + lv;
+  const bool sol = a >= 2;
+  const bool active = !(sol && !p.do_solar);
+  const double *src = a == 0 ? p.ir_fup_a : a == 1 ? p.ir_fdn_a : a == 2 ? p.sol_fup_a : p.sol_fdn_a;
+  const double *freq = sol ? p.sol_freq : p.ir_freq;
+  const int lo = sol ? p.sol_lo : p.ir_lo, cnt = sol ? p.sol_n : p.ir_n;
+  if (active && i < nl) {
+    for (int ch = cg; ch < p.nchunk; ch += INT_CG) {
+      const int l0 = lo + ch * INT_CHUNK;
+      const int l1 = min(lo + cnt, l0 + INT_CHUNK);
+      double acc = 0.0;
+      if (l0 < l1) {
+        double v[INT_CHUNK];
+#pragma unroll
+        for (int k = 0; k < INT_CHUNK; k++) v[k] = (l0 + k < l1) ? src[(size_t)(l0 + k) * nl + i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < INT_CHUNK; k++)
+          if (l0 + k < l1) acc = __builtin_fma(v[k], freq[l0 + k] - freq[l0 + k + 1], acc);
+      }
+      s_part[((size_t)a * p.nchunk + ch) * INT_LV + lv] = acc;
+    }
+  }
+  __syncthreads();
+  double *s_tot = s_part + (size_t)4 * p.nchunk * INT_LV;
+  if (cg == 0 && i < nl) {
+    double acc;
+    if (active) {
+      acc = 0.0;
+      for (int k = 0; k < p.nchunk; k++) acc = acc + s_part[((size_t)a * p.nchunk + k) * INT_LV + lv];
+      p.flux_n[a * nl + i] = acc;
+    } else {
+      acc = p.flux_n[a * nl + i];  // solar rows of the last solar call (clima_radtran.f90:286-289)
+    }
+    s_tot[a * INT_LV + lv] = acc;
+  }
+  __syncthreads();
+  if (p.f_total && grp == 0 && i < nl)
+    p.f_total[i] = (s_tot[3 * INT_LV + lv] - s_tot[2 * INT_LV + lv]) + (s_tot[1 * INT_LV + lv] - s_tot[0 * INT_LV + lv]);
+}
+
 void launch_integrate(const IntegrateParams &p, hipStream_t s) {
+  const int nl = p.nz + 1;
+  const size_t lds = sizeof(double) * ((size_t)4 * p.nchunk * INT_LV + 4 * INT_LV);
+  if (lds <= 64 * 1024) {
+    hipLaunchKernelGGL(k_integrate_one, dim3((nl + INT_LV - 1) / INT_LV), dim3(INT_LV * 4 * INT_CG), lds, s, p);
+    return;
+  }
   hipLaunchKernelGGL(k_integrate_partial, dim3(p.nchunk, 4), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_integrate_final, dim3(1), dim3(1024), 0, s, p);
 }
