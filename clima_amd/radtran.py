@@ -146,6 +146,14 @@ class Radtran:
         self.nw = t.nw
         self.ngauss = t.ng
 
+    @classmethod
+    def from_files(cls, settings_f, star_f, num_zenith_angles, surface_albedo, nz, datadir):
+        """`Radtran(settings_f, star_f, num_zenith_angles, surface_albedo, nz, datadir, err)`
+        (src/radtran/clima_radtran.f90:98-126): species and opacities from the settings YAML, tables
+        from a `photochem_clima_data`-style directory (clima_amd/data_loader.py)."""
+        from . import data_loader
+        return cls(data_loader.load_tables(settings_f, star_f, datadir), nz, num_zenith_angles, surface_albedo)
+
     def __del__(self):
         if getattr(self, "_ptr", None) is not None and self._ptr.value:
             self._L.deallocate_radtran(self._ptr)

@@ -344,6 +344,23 @@ def test_adiabat_style_doubled_radiative_grid(O, small_tables):
     _compare(r, o, col)
 
 
+def test_constructed_from_a_data_directory(O, tmp_path):
+    # the reference constructor's argument list: settings YAML + star file + data directory
+    # (clima_radtran.f90:98-126), tables through clima_amd/data_loader.py
+    import os
+    from clima_amd import data_loader as D
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    from datadir_fixture import write_datadir
+    root = str(tmp_path)
+    write_datadir(root, S.modern_earth_tables(nw=24, seed=12))
+    settings, star = os.path.join(root, "settings.yaml"), os.path.join(root, "star.txt")
+    r = Radtran.from_files(settings, star, 3, 0.2, 40, root)
+    o = O.OracleRadtran(D.load_tables(settings, star, root), 40, 3, 0.2)
+    assert r.species_names == list(S.MODERN_EARTH_SPECIES) and r.particle_names == ["HCaer1"]
+    _compare(r, o, S.modern_earth_column(40))
+
+
 def test_radiation_enhancement_and_bolometric(O, small_tables):
     from clima_amd import synthetic as S
     col = S.modern_earth_column(50)
