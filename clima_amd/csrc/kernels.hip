@@ -220,6 +220,21 @@ __device__ __forceinline__ double lerp1(const double *f, int i, double q) {
 }
 
 constexpr int OP_THREADS = 256;
+
+// Device-scope accesses for data handed from one block to another INSIDE a launch (k_fused):
+// stores write through and loads bypass the per-XCD L2, so no cache-wide writeback /
+// invalidate (what an agent-scope fence costs on this part) is needed.
+template <bool COHERENT>
+__device__ __forceinline__ void st_opr(double *p, double v) {
+  if constexpr (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COHERENT>
+__device__ __forceinline__ double ld_opr(const double *p) {
+  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
 #ifdef CLIMA_STAMPS
 __device__ long long *g_stamp_buf = nullptr;
 __device__ int g_stamp_step = 0;
@@ -356,8 +371,8 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
   for (int q = 1; q < 8; q++) out[q] = (Ik[q] - Ik[q - 1]) * rW[q];
 }
 
-template <bool MULTI, bool CUSTOM>
-__global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
+template <bool MULTI, bool CUSTOM, bool COHERENT>
+__device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int block) {
   constexpr int NG = 8;
   __shared__ double sI[NG][OP_THREADS];  // per-lane private slots (slot-major: conflict-free)
   __shared__ double s_wxy[NG * NG];
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   const int nz = p.nz;
   const long total = (long)p.nbins * nz;
   const ColumnDev &c = p.col;
-  long t = (long)blockIdx.x * OP_THREADS + tid;
+  long t = (long)block * OP_THREADS + tid;
   const bool valid = t < total;
   if (!valid) t = total - 1;
   const int l = p.bin_lo + (int)(t / nz);
@@ -515,7 +530,7 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
   STAMP(p.stamps, 20);
 #ifdef CLIMA_STAMPS
   if (p.stamps && (tid & 63) == 0) {
-    const long w = (long)blockIdx.x * (OP_THREADS / 64) + (tid >> 6);
+    const long w = (long)block * (OP_THREADS / 64) + (tid >> 6);
     p.stamps[64 + 2 * w] = wt0;
     p.stamps[64 + 2 * w + 1] = __builtin_amdgcn_s_memrealtime();
   }
@@ -531,13 +546,18 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
       double w0;
       if (tau <= TAU_MIN) w0 = 0.0;
       else w0 = fmin(MAX_W0, (tausg + tausp + tausc) / tau);
-      p.tau[base + (size_t)g * nz] = tau;
-      p.w0[base + (size_t)g * nz] = w0;
+      st_opr<COHERENT>(&p.tau[base + (size_t)g * nz], tau);
+      st_opr<COHERENT>(&p.w0[base + (size_t)g * nz], w0);
       tb = tb + tau * wbin[g];
     }
-    p.tau_band[(size_t)l * nz + n] = tb;
-    p.g[(size_t)l * nz + n] = gt;
+    st_opr<COHERENT>(&p.tau_band[(size_t)l * nz + n], tb);
+    st_opr<COHERENT>(&p.g[(size_t)l * nz + n], gt);
   }
+}
+
+template <bool MULTI, bool CUSTOM>
+__global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
+  opacity8_body<MULTI, CUSTOM, false>(p, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1302,14 +1322,15 @@ __device__ __forceinline__ M7 m7_shfl_down(const M7 &a, int d) {
 
 constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
 
-template <int LMAX, bool SOLAR>
-__device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const int bin_local, double *lds) {
+template <int LMAX, bool SOLAR, bool COHERENT>
+__device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const int bin_local, double *lds,
+                                                 const int gy, const int bz) {
   const int nz = p.nz, ng = p.ng, nl = nz + 1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr bool solar = SOLAR;
   const int ll = (solar ? p.sol_lo : p.ir_lo) + bin_local;
   const int l = (solar ? p.sol_start : p.ir_start) + ll;  // opacity bin (radiate.f90:57)
-  const int c_raw = p.col_base + blockIdx.y * TSW_COLS + wave;
+  const int c_raw = p.col_base + gy * TSW_COLS + wave;
   const bool col_on = c_raw < ng;
   const int c = col_on ? c_raw : ng - 1;
   const double wcol = col_on ? p.wbin[c] : 0.0;  // g-point weight (radiate.f90:122-126)
@@ -1333,7 +1354,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 #pragma unroll
     for (int t = 0; t < LMAX; t++)
       if (t < len) {
-        const double tau_in = tauL[a + t], w0_in = w0L[a + t], gt_in = gL[a + t];
+        const double tau_in = ld_opr<COHERENT>(&tauL[a + t]), w0_in = ld_opr<COHERENT>(&w0L[a + t]), gt_in = ld_opr<COHERENT>(&gL[a + t]);
         tot = tot + tau_in * (1.0 - w0_in * gt_in * gt_in);
       }
     double incl = tot;
@@ -1354,8 +1375,8 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
   }
   const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64 (IR)
   // batched shared-opacity IR launches: blockIdx.z selects the temperature column (strides 0 otherwise)
-  const double *Tcol = p.T + (size_t)blockIdx.z * p.b_T;
-  const double *Tsfc = p.T_surface + (size_t)blockIdx.z * p.b_Ts;
+  const double *Tcol = p.T + (size_t)bz * p.b_T;
+  const double *Tsfc = p.T_surface + (size_t)bz * p.b_Ts;
 
   // ---- layer by layer: optical coefficients and source terms of layer t, then the rows of
   //      the chunk's system that become complete with it, eliminated downward at once
@@ -1379,7 +1400,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
       rc[2 * t] = rc[2 * t + 1] = rd[2 * t] = rd[2 * t + 1] = rl[2 * t] = rl[2 * t + 1] = 0.0;
       if (t < len) {
         const int i = a + t;
-        const double tau_in = tauL[i], w0_in = w0L[i], gt_in = gL[i];
+        const double tau_in = ld_opr<COHERENT>(&tauL[i]), w0_in = ld_opr<COHERENT>(&w0L[i]), gt_in = ld_opr<COHERENT>(&gL[i]);
         double cp0, cm0, Ssfc = 0.0;
         if constexpr (solar) {
           // delta-Eddington (:38-40), quadrature coefficients (:43-44), lambda, Gamma (:50-51)
@@ -1602,14 +1623,14 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
       if (split) { atomicAdd(&p.sol_fup_a[o], fu); atomicAdd(&p.sol_fdn_a[o], fd); atomicAdd(&p.sol_amean[o], am); }
       else { p.sol_fup_a[o] = fu; p.sol_fdn_a[o] = fd; p.sol_amean[o] = am; }
     } else {
-      const size_t ob = o + (size_t)blockIdx.z * p.b_out;
+      const size_t ob = o + (size_t)bz * p.b_out;
       if (split) { atomicAdd(&p.ir_fup_a[ob], fu); atomicAdd(&p.ir_fdn_a[ob], fd); }
       else { p.ir_fup_a[ob] = fu; p.ir_fdn_a[ob] = fd; }
     }
   }
-  if (blockIdx.y == 0 && p.col_base == 0 && p.b_out == 0) {
+  if (gy == 0 && p.col_base == 0 && p.b_out == 0) {
     double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
-    for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = p.tau_band[(size_t)l * nz + (nz - 1 - i)];
+    for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = ld_opr<COHERENT>(&p.tau_band[(size_t)l * nz + (nz - 1 - i)]);
   }
 }
 
@@ -1618,8 +1639,8 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 template <int LMAX>
 __global__ __launch_bounds__(64 * TSW_COLS) void k_twostream_w(TwoStreamParams p) {
   extern __shared__ __align__(16) double lds[];  // [3][TSW_COLS][nz+1] weighted level values
-  if ((int)blockIdx.x < p.n_sol) twostream_w_body<LMAX, true>(p, (int)blockIdx.x, lds);
-  else twostream_w_body<LMAX, false>(p, (int)blockIdx.x - p.n_sol, lds);
+  if ((int)blockIdx.x < p.n_sol) twostream_w_body<LMAX, true, false>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
+  else twostream_w_body<LMAX, false, false>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
@@ -1669,6 +1690,80 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
     const dim3 g(grid, per_launch, p.b_ncol > 0 ? p.b_ncol : 1);
     if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4>), g, blk, lds, s, p);
     else hipLaunchKernelGGL((k_twostream_w<8>), g, blk, lds, s, p);
+  }
+  return true;
+}
+
+
+// ------------------------------------------------------------------------------------
+// k_fused: opacity and two-stream work of one call in ONE grid.  Blocks [0, n_op) are the
+// opacity blocks of k_opacity8; the blocks after them are the two-stream blocks of
+// k_twostream_w (solar bins first), each of which first waits until the opacity blocks that
+// cover its bin have published their results.  The opacity launch holds two waves per SIMD and
+// its second residency round is half empty; here the two-stream blocks move into those slots
+// as soon as they free up instead of waiting for the whole launch to drain.
+// Forward progress: blocks are dispatched in index order, so whatever a two-stream block waits
+// for is already running or done, and opacity blocks wait for nothing.  The wait is bounded
+// all the same: on expiry the block reports through the error flag and returns.
+// ------------------------------------------------------------------------------------
+template <bool MULTI, bool CUSTOM>
+__global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoStreamParams ts, FusedParams fp) {
+  extern __shared__ __align__(16) double lds[];
+  if ((int)blockIdx.x < fp.n_op) {
+    opacity8_body<MULTI, CUSTOM, true>(op, (int)blockIdx.x);
+    // the opr stores above went out at device scope (write-through); wait until they are
+    // acknowledged, then let every wave of the block arrive before the flag goes up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): this wave's write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&fp.done[blockIdx.x], fp.call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int nb = ts.n_sol + ts.n_ir;
+  const int b = (int)blockIdx.x - fp.n_op;
+  const int gy = b / nb, bl = b - gy * nb;
+  const bool solar = bl < ts.n_sol;
+  const int ll = solar ? ts.sol_lo + bl : ts.ir_lo + (bl - ts.n_sol);
+  const int l = (solar ? ts.sol_start : ts.ir_start) + ll;
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    const long t0 = (long)(l - op.bin_lo) * op.nz;
+    const int d0 = (int)(t0 / OP_THREADS), d1 = (int)((t0 + op.nz - 1) / OP_THREADS);
+    int ok = 1;
+    for (int d = d0; d <= d1 && ok; d++) {
+      int spins = 0;
+      while (__hip_atomic_load(&fp.done[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fp.call_id) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > fp.max_spins) { ok = 0; break; }
+      }
+    }
+    if (!ok) atomicMax(fp.err_flag, fp.call_id);
+    s_ok = ok;
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  if (solar) twostream_w_body<4, true, true>(ts, bl, lds, gy, 0);
+  else twostream_w_body<4, false, true>(ts, bl - ts.n_sol, lds, gy, 0);
+}
+
+// false when the configuration is outside what the fused form covers (the caller then uses the
+// separate launches)
+bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s) {
+  if (op.ng != 8 || (ts.nz + 63) / 64 > 4 || ts.nzen > MAX_ZEN) return false;
+  const long total = (long)op.nbins * op.nz;
+  const int nb = ts.n_sol + ts.n_ir;
+  if (total <= 0 || nb <= 0) return false;
+  fp.n_op = (int)((total + OP_THREADS - 1) / OP_THREADS);
+  const int groups = (ts.ng + TSW_COLS - 1) / TSW_COLS;  // 2
+  ts.col_base = 0; ts.accumulate = 1;
+  const size_t lds = sizeof(double) * 3 * TSW_COLS * ((size_t)ts.nz + 1);
+  const dim3 grid(fp.n_op + nb * groups), blk(OP_THREADS);
+  if (op.cust.on) {
+    if (op.multi_edge) hipLaunchKernelGGL((k_fused<true, true>), grid, blk, lds, s, op, ts, fp);
+    else hipLaunchKernelGGL((k_fused<false, true>), grid, blk, lds, s, op, ts, fp);
+  } else {
+    if (op.multi_edge) hipLaunchKernelGGL((k_fused<true, false>), grid, blk, lds, s, op, ts, fp);
+    else hipLaunchKernelGGL((k_fused<false, false>), grid, blk, lds, s, op, ts, fp);
   }
   return true;
 }

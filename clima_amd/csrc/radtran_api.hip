@@ -159,6 +159,8 @@ struct Radtran {
   int op_lo = 0, op_n = 0, ir_lo = 0, ir_n = 0, sol_lo = 0, sol_n = 0;
   // stream + profiling
   hipStream_t stream = nullptr;
+  bool fused = false;              // opacity + two-stream in one grid (k_fused)
+  DevBuf<int> d_done;              // per opacity block: call id of its last completed run
   int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (k_opacity) only
   struct Ev { hipEvent_t a, b; int id; };
   std::vector<Ev> pending;
@@ -393,7 +395,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   upload_fields(r);
   const int nz = r->nz;
   ColumnDev col = column_dev(r);
-  bool pre_zeroed = false;
+  bool pre_zeroed = false, fused_done = false;
   if (compute_opacity) {
     PrepParams pp;
     std::memset(&pp, 0, sizeof(pp));
@@ -456,7 +458,14 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     op.stamps = r->d_stamps.p;
 #endif
     op.tau = r->d_tau.p; op.w0 = r->d_w0.p; op.g = r->d_g.p; op.tau_band = r->d_tau_band.p;
-    {
+    if (r->fused && pre_zeroed) {
+      TwoStreamParams tsf = make_twostream_params(r, col, compute_solar);
+      FusedParams fp{0, pp.call_id, 400000, r->d_done.p, r->d_err.p};
+      KernelTimer t(r, 1);
+      fused_done = launch_fused(op, tsf, fp, r->stream);
+      t.stop();
+    }
+    if (!fused_done) {
       KernelTimer t(r, 1);
       if (!launch_opacity(op, r->stream))
         throw HipFail{"k-distributions with " + std::to_string(r->ng) + " g-points are not supported (1..32)"};
@@ -466,7 +475,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   }
 
   TwoStreamParams ts = make_twostream_params(r, col, compute_solar);
-  {
+  if (!fused_done) {
     KernelTimer t(r, 2);
     // default: wave-per-column kernel; CLIMA_HIP_TS_MODE=block selects the workgroup-per-bin form
     const char *mode = getenv("CLIMA_HIP_TS_MODE");
@@ -793,6 +802,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   HIPCHK(hipGetDeviceCount(&dev_count));
   if (dev_count < 1) throw HipFail{"no HIP device available: the Radtran hot path has no CPU fallback"};
   HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  if (const char *f = getenv("CLIMA_HIP_FUSED")) r->fused = atoi(f) != 0;
 
   // ---- tables to HBM + interpolation slots
   r->slots.clear();
@@ -864,6 +874,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   r->d_absw.alloc((size_t)std::max<size_t>(1, r->abs_entries.size()) * nz);
   r->d_src.alloc(nz); r->d_ix.alloc((size_t)(r->nslots + 1) * nz); r->d_q.alloc((size_t)(r->nslots + 1) * nz);
   r->d_err.alloc(1); r->d_err.zero();
+  r->d_done.alloc(((size_t)nw * nz + 255) / 256 + 1); r->d_done.zero();
 #ifdef CLIMA_STAMPS
   r->d_stamps.alloc(64 + 2 * 8192); r->d_stamps.zero();
 #endif

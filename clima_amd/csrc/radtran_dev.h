@@ -162,6 +162,15 @@ struct TwoStreamParams {
   double *sol_fup_a, *sol_fdn_a, *sol_amean, *sol_tau_band;
 };
 
+// fused opacity + two-stream launch (k_fused)
+struct FusedParams {
+  int n_op;        // opacity blocks at the front of the grid (launcher)
+  int call_id;     // value an opacity block publishes in done[block] when its results are out
+  int max_spins;   // bound of a two-stream block's wait
+  int *done;       // [n_op]
+  int *err_flag;
+};
+
 struct IntegrateParams {
   int nz;
   int nw_ir, nw_sol;
@@ -191,6 +200,7 @@ void launch_prep(const PrepParams &p, hipStream_t s);
 bool launch_opacity(const OpacityParams &p, hipStream_t s);
 bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
 bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed);
+bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s);
 int twostream_w_groups(int ng);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
 void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t s);
