@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 KERNELS = ["prep", "opacity", "twostream", "integrate"]
 # HBM bytes of one k_opacity8 launch on this exact workload from the PMC passes committed under
 # profiles/ (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; bench.py cannot collect counters itself)
-PMC_TRAFFIC_BYTES = (1.640e4 + 4.681e4) * 1024.0
+PMC_TRAFFIC_BYTES = {"opacity": (1.640e4 + 4.681e4) * 1024.0}
 PMC_TRAFFIC_SOURCE = "profiles/r01d_pmc_summary.md: k_opacity8 FETCH_SIZE 1.640e4 KiB + WRITE_SIZE 4.681e4 KiB per launch"
 
 
@@ -171,7 +171,10 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = args.steps / dt
-        per_kernel_us = {k: (1e3 * ms / n if n else 0.0) for k, (ms, n) in zip(KERNELS, kt)}
+        names = list(KERNELS)
+        if rad.fused:   # opacity and two-stream work run as one grid (k_fused), timed as kernel id 1
+            names[1] = "fused"
+        per_kernel_us = {k: (1e3 * ms / n if n else 0.0) for k, (ms, n) in zip(names, kt) if n}
         dom = max(per_kernel_us, key=per_kernel_us.get)
         ab = rad.algorithmic_bytes()
         # algorithmic bytes of one call: distinct table nodes + inputs + outputs,
@@ -182,7 +185,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": b_alg / dur / 1e9 if dur > 0 else 0.0,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (b_alg / dur / 1e9) / HBM_PEAK_GBS if dur > 0 else 0.0,
-                    "traffic": PMC_TRAFFIC_BYTES if (dom == "opacity" and not dist_on and (nz, nzen) == (200, 8)) else None,
+                    "traffic": PMC_TRAFFIC_BYTES.get(dom) if (not dist_on and (nz, nzen) == (200, 8)) else None,
                     "traffic_source": PMC_TRAFFIC_SOURCE,
                     "algorithmic_bytes": b_alg, "kernel_us": per_kernel_us,
                     "whole_call_frac": (b_alg / (dt / args.steps) / 1e9) / HBM_PEAK_GBS}

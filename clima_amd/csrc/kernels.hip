@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   __shared__ int s_ok;
   if (threadIdx.x == 0) {
     const long t0 = (long)(l - op.bin_lo) * op.nz;
-    const int d0 = (int)(t0 / OP_THREADS), d1 = (int)((t0 + op.nz - 1) / OP_THREADS);
+    const int d0 = max((int)(t0 / OP_THREADS), 0), d1 = min((int)((t0 + op.nz - 1) / OP_THREADS), fp.n_op - 1);
     int ok = 1;
     for (int d = d0; d <= d1 && ok; d++) {
       int spins = 0;

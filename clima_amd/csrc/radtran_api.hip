@@ -159,7 +159,7 @@ struct Radtran {
   int op_lo = 0, op_n = 0, ir_lo = 0, ir_n = 0, sol_lo = 0, sol_n = 0;
   // stream + profiling
   hipStream_t stream = nullptr;
-  bool fused = false;              // opacity + two-stream in one grid (k_fused)
+  bool fused = true;               // opacity + two-stream in one grid (k_fused); CLIMA_HIP_FUSED=0 or radtran_fused_set turns it off
   DevBuf<int> d_done;              // per opacity block: call id of its last completed run
   int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (k_opacity) only
   struct Ev { hipEvent_t a, b; int id; };
@@ -766,6 +766,15 @@ void radtran_set_custom_optical_properties(void *ptr, const int *dim_wv, const d
   r->d_cust_axis.upload(lp); r->d_cust_dtau.upload(tab[0]); r->d_cust_w0.upload(tab[1]); r->d_cust_g0.upload(tab[2]);
   r->cust_on = true;
   CATCH(err)
+}
+
+void radtran_fused_set(void *ptr, const int *enable) {
+  Radtran *r = as_rad(ptr);
+  if (r) r->fused = (*enable != 0);
+}
+void radtran_fused_get(void *ptr, int *enabled) {
+  Radtran *r = as_rad(ptr);
+  *enabled = (r && r->fused) ? 1 : 0;
 }
 
 // clima/fortran/Radtran.f90:109-118

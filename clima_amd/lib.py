@@ -35,6 +35,8 @@ SIGNATURES = {
     "radtran_apply_radiation_enhancement": [_vp, _dp],
     "radtran_set_custom_optical_properties": [_vp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, _err],
     "radtran_unset_custom_optical_properties": [_vp],
+    "radtran_fused_set": [_vp, _ip],
+    "radtran_fused_get": [_vp, _ip],
     "radtran_radiate_ir_batch": [_vp, _ip, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _err],
     "radtran_upload_column": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],
     "radtran_radiate_resident": [_vp, _ip, _ip, _err],

@@ -274,6 +274,17 @@ class Radtran:
         self._L.radtran_bin_shard_get(self._ptr, *[C.byref(x) for x in v])
         return tuple(x.value for x in v)
 
+    @property
+    def fused(self):
+        """True: opacity + two-stream of a compute_opacity call run as one grid (k_fused)."""
+        v = C.c_int()
+        self._L.radtran_fused_get(self._ptr, C.byref(v))
+        return bool(v.value)
+
+    @fused.setter
+    def fused(self, on):
+        self._L.radtran_fused_set(self._ptr, _i(1 if on else 0))
+
     def flux_tensor(self):
         """The packed level fluxes [ir_up, ir_dn, sol_up, sol_dn][nz+1] as a torch CUDA tensor
         aliasing the library's buffer (the RCCL all-reduce payload of a bin-sharded run)."""

@@ -141,6 +141,11 @@ void radtran_finish_reduced(void *ptr, char *err);
 void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
                               const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
                               double *f_total, char *err);
+/* Launch form of a compute_opacity call: 1 (default) = opacity and two-stream work in one grid
+ * (k_fused: two-stream blocks start as soon as the opacity blocks of their bin are done),
+ * 0 = one launch per kernel.  Same results to rounding; CLIMA_HIP_FUSED=0 sets the default off. */
+void radtran_fused_set(void *ptr, const int *enable);
+void radtran_fused_get(void *ptr, int *enabled);
 /* HIP stream the handle launches on (for callers that order other work against it) */
 void radtran_stream_get(void *ptr, void **stream);
 /* per-kernel device time (HIP events on the handle's stream).  enable = 1 records events

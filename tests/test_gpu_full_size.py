@@ -101,3 +101,15 @@ def test_bin_sharded_partials_add_up(nominal):
     r.set_bin_shard(0, 1)
     assert covered == tb.nw
     assert np.allclose(acc, full, rtol=1e-12, atol=1e-9)
+
+
+def test_separate_launch_form_at_full_size(nominal):
+    """config 2 with one launch per kernel (the form the fused grid replaces) gives the same TOA
+    fluxes to rounding."""
+    tb, r, col = nominal
+    r.fused = True
+    a = r.TOA_fluxes(*col.args())
+    r.fused = False
+    b = r.TOA_fluxes(*col.args())
+    r.fused = True
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(a[1])

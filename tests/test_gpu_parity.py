@@ -280,6 +280,30 @@ def test_workgroup_per_bin_kernel_agrees(O, small_tables, monkeypatch):
     _compare(r, o, S.modern_earth_column(50))
 
 
+@pytest.mark.parametrize("nz,nw", [(50, 40), (200, 60), (13, 7)])
+def test_fused_and_separate_launch_forms(O, nz, nw, monkeypatch):
+    # default: opacity + two-stream blocks in one grid (k_fused, block-to-block hand-off inside the
+    # launch); radtran_fused_set(0) / CLIMA_HIP_FUSED=0: one launch per kernel.  Same opacities bit
+    # for bit (same code), same fluxes to rounding, both within tolerance of the oracle.
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    tb = S.modern_earth_tables(nw=nw, seed=31)
+    col = S.modern_earth_column(nz)
+    r, o = _pair(O, tb, nz, 3, 0.2)
+    assert r.fused
+    _compare(r, o, col)
+    opr_f = [a.copy() for a in r.opr()]
+    flux_f = np.array(r.f_total)
+    r.fused = False
+    assert not r.fused
+    _compare(r, o, col)
+    for a, b in zip(opr_f, r.opr()):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(np.array(r.f_total), flux_f, rtol=1e-11, atol=1e-9 * np.max(np.abs(flux_f)))
+    monkeypatch.setenv("CLIMA_HIP_FUSED", "0")
+    assert not Radtran(tb, nz, 3, 0.2).fused
+
+
 def test_state_carried_between_calls(O, small_tables):
     # compute_opacity=False reuses opr; compute_solar=False reuses wrk_sol (clima_radtran.f90:255-289)
     from clima_amd import synthetic as S
