@@ -33,8 +33,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 KERNELS = ["prep", "opacity", "twostream", "integrate"]
 # HBM bytes of one k_opacity8 launch on this exact workload from the PMC passes committed under
 # profiles/ (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; bench.py cannot collect counters itself)
-PMC_TRAFFIC_BYTES = {"opacity": (1.640e4 + 4.681e4) * 1024.0}
-PMC_TRAFFIC_SOURCE = "profiles/r01d_pmc_summary.md: k_opacity8 FETCH_SIZE 1.640e4 KiB + WRITE_SIZE 4.681e4 KiB per launch"
+PMC_TRAFFIC_BYTES = {"fused": (3.634e4 + 7.433e4) * 1024.0,      # profiles/r01e_pmc_summary.md, k_fused
+                     "opacity": (1.640e4 + 4.681e4) * 1024.0}    # profiles/r01d_pmc_summary.md, k_opacity8
+PMC_TRAFFIC_SOURCE = "FETCH_SIZE + WRITE_SIZE (KiB) of the dominant kernel per launch: profiles/r01e_pmc_summary.md (k_fused), profiles/r01d_pmc_summary.md (k_opacity8)"
 
 
 def main():
