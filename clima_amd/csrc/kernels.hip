@@ -1322,7 +1322,7 @@ __device__ __forceinline__ M7 m7_shfl_down(const M7 &a, int d) {
 
 constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
 
-template <int LMAX, bool SOLAR, bool COHERENT>
+template <int LMAX, bool SOLAR, bool COHERENT, int NZMAX>
 __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const int bin_local, double *lds,
                                                  const int gy, const int bz) {
   const int nz = p.nz, ng = p.ng, nl = nz + 1;
@@ -1388,7 +1388,9 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
     E4 u = make_e(0.0, 0.0);
     double cpb_u = 0.0, cmb_u = 0.0;
     double bpl_top = 0.0;  // IR: Planck at the top level of the current layer
-    constexpr int NZMAX = 0;  // zenith angles whose direct-beam transmission is carried layer to layer (0: recompute)
+    // NZMAX: zenith angles whose direct-beam transmission exp(-tauc/u0) is carried from layer to
+    // layer inside the lane's chunk instead of recomputed (costs 2*NZMAX VGPRs: worth it only where
+    // the register budget is there anyway, i.e. in k_fused)
     double etc[NZMAX + 1];
 #pragma unroll
     for (int z = 0; z < NZMAX; z++) etc[z] = 1.0;
@@ -1639,8 +1641,8 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 template <int LMAX>
 __global__ __launch_bounds__(64 * TSW_COLS) void k_twostream_w(TwoStreamParams p) {
   extern __shared__ __align__(16) double lds[];  // [3][TSW_COLS][nz+1] weighted level values
-  if ((int)blockIdx.x < p.n_sol) twostream_w_body<LMAX, true, false>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
-  else twostream_w_body<LMAX, false, false>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
+  if ((int)blockIdx.x < p.n_sol) twostream_w_body<LMAX, true, false, 0>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
+  else twostream_w_body<LMAX, false, false, 0>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
@@ -1706,6 +1708,9 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
 // for is already running or done, and opacity blocks wait for nothing.  The wait is bounded
 // all the same: on expiry the block reports through the error flag and returns.
 // ------------------------------------------------------------------------------------
+#ifndef FUSED_NZMAX
+#define FUSED_NZMAX 8
+#endif
 template <bool MULTI, bool CUSTOM>
 __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoStreamParams ts, FusedParams fp) {
   extern __shared__ __align__(16) double lds[];
@@ -1742,8 +1747,8 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   }
   __syncthreads();
   if (!s_ok) return;
-  if (solar) twostream_w_body<4, true, true>(ts, bl, lds, gy, 0);
-  else twostream_w_body<4, false, true>(ts, bl - ts.n_sol, lds, gy, 0);
+  if (solar) twostream_w_body<4, true, true, FUSED_NZMAX>(ts, bl, lds, gy, 0);
+  else twostream_w_body<4, false, true, 0>(ts, bl - ts.n_sol, lds, gy, 0);
 }
 
 // false when the configuration is outside what the fused form covers (the caller then uses the
