@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from clima_amd import synthetic as S  # noqa: E402
 from clima_amd.radtran import Radtran  # noqa: E402
 from oracle import oracle as O  # noqa: E402

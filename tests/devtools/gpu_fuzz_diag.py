@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Developer diagnostic: GPU-vs-oracle flux error of fuzz cases as a function of ir_tau_min."""
 import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 import importlib.util
-spec = importlib.util.spec_from_file_location("fz", os.path.join(os.path.dirname(__file__), "..", "tests", "test_gpu_fuzz.py"))
+spec = importlib.util.spec_from_file_location("fz", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "test_gpu_fuzz.py"))
 m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 from clima_amd.radtran import Radtran
 from oracle import oracle as O

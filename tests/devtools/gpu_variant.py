@@ -3,7 +3,7 @@
 library (experiments compiled with extra -D flags into csrc/<name>.so).
 Usage: gpu_variant.py <lib file name in clima_amd/csrc> [reps]"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from clima_amd import lib
 name = sys.argv[1]
