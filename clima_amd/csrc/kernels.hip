@@ -511,7 +511,7 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
     if (s == 0) {
 #pragma unroll
       for (int g = 0; g < NG; g++) tk[g] = kc[g];
-    } else if (!(p.debug_skip & 1)) {
+    } else {
 #ifdef CLIMA_STAMPS
       if (blockIdx.x == 100 && threadIdx.x == 0) { g_stamp_buf = p.stamps; g_stamp_step = s; }
 #endif
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_twostream(TwoStreamParams p) {
         const double gam2 = sqrt3 * kw0[k] * (1.0 - kgt[k]) / 2.0;
         const double lam2 = klam[k] * klam[k];
         double CP0 = 0.0, CPB = 0.0, CM0 = 0.0, CMB = 0.0, DIR = 0.0, DIRU = 0.0;
-        for (int z = 0; z < ((p.debug_skip & 2) ? 1 : p.nzen); z++) {
+        for (int z = 0; z < p.nzen; z++) {
           const double u0 = p.zen_u[z], wz = p.zen_w[z], iu = p.zen_iu[z];
           const double gam3 = (1.0 - sqrt3 * kgt[k] * u0) / 2.0;
           const double gam4 = 1.0 - gam3;
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_twostream(TwoStreamParams p) {
   __syncthreads();
 
   // ---- tridiagonal solve by one wave: S chunks x nc columns lanes
-  if (tid < S * nc && !(p.debug_skip & 1)) dd_solve(s, nz, nc, S, tid, Rsfc);
+  if (tid < S * nc) dd_solve(s, nz, nc, S, tid, Rsfc);
   __syncthreads();
 
   // ---- level fluxes (:143-148, :288-293) and mean intensity (:135-140)

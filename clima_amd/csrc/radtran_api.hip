@@ -369,7 +369,6 @@ TwoStreamParams make_twostream_params(Radtran *r, const ColumnDev &col, bool com
   const int nz = r->nz;
   std::memset(&ts, 0, sizeof(ts));
   ts.nz = nz; ts.ng = r->ng;
-  if (const char *dbg = getenv("CLIMA_HIP_DEBUG_SKIP_TS")) ts.debug_skip = atoi(dbg);
   if (const char *nc = getenv("CLIMA_HIP_TS_NCOLS")) ts.ncols = atoi(nc);
   ts.n_sol = compute_solar ? r->sol_n : 0; ts.sol_lo = r->sol_lo;
   ts.n_ir = r->ir_n; ts.ir_lo = r->ir_lo;
@@ -441,7 +440,6 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     std::memset(&op, 0, sizeof(op));
     op.nz = nz; op.nw = r->nw; op.ng = r->ng; op.nsp = r->nsp; op.np = r->np;
     op.bin_lo = r->op_lo; op.nbins = r->op_n;
-    if (const char *dbg = getenv("CLIMA_HIP_DEBUG_SKIP_OP")) op.debug_skip = atoi(dbg);
     op.nk = (int)r->k.size(); op.nray = (int)r->ray.size(); op.npart = (int)r->part.size();
     for (size_t i = 0; i < r->k.size(); i++)
       op.k[i] = KDev{r->k[i]->d_log10k.p, r->k[i]->sp, r->k[i]->nP, r->k[i]->nT, (int)(2 * i), (int)(2 * i + 1)};

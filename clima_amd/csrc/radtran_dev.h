@@ -99,7 +99,6 @@ struct CustomDev {
 
 struct OpacityParams {
   int nz, nw, ng, nsp, np;
-  int debug_skip;  // developer ablation mask (0 in production)
   int bin_lo, nbins;  // opacity bins handled by this launch
   int nk, nray, npart;
   KDev k[MAX_K];
@@ -130,7 +129,6 @@ struct PrepParams {
 
 struct TwoStreamParams {
   int nz, ng;
-  int debug_skip;                          // developer ablation mask (0 in production)
   int ncols, nchunks, nc_shift;            // g-point columns per block, chunks per column, log2(ncols) or -1 (launcher)
   int col_base, accumulate;                // wave kernel: first g-point of this launch; add into the outputs (launcher)
   // batched shared-opacity IR launches (wave kernel): gridDim.z = b_ncol temperature columns,
