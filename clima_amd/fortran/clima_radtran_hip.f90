@@ -74,6 +74,7 @@ module clima_radtran_hip
     procedure :: skin_temperature => Radtran_skin_temperature
     procedure :: equilibrium_temperature => Radtran_equilibrium_temperature
     procedure :: apply_radiation_enhancement => Radtran_apply_radiation_enhancement
+    procedure :: radiate_ir_batch => Radtran_radiate_ir_batch
     procedure :: set_custom_optical_properties => Radtran_set_custom_optical_properties
     procedure :: unset_custom_optical_properties => Radtran_unset_custom_optical_properties
     procedure :: destroy => Radtran_destroy
@@ -147,6 +148,14 @@ module clima_radtran_hip
     subroutine c_radtran_apply_radiation_enhancement(ptr, rad_enhancement) bind(c, name="radtran_apply_radiation_enhancement")
       import; type(c_ptr), value :: ptr
       real(c_double), intent(in) :: rad_enhancement
+    end subroutine
+    subroutine c_radtran_radiate_ir_batch(ptr, ncol, T_surface, dim1_T, dim2_T, T, fup_n, fdn_n, f_total, err) &
+                                          bind(c, name="radtran_radiate_ir_batch")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: ncol, dim1_T, dim2_T
+      real(c_double), intent(in) :: T_surface(*), T(*)
+      real(c_double), intent(out) :: fup_n(*), fdn_n(*), f_total(*)
+      character(c_char), intent(out) :: err(*)
     end subroutine
     subroutine c_radtran_set_custom_optical_properties(ptr, dim_wv, wv, dim_P, P, dim1_t, dim2_t, dtau_dz, &
                                                        dim1_w, dim2_w, w0, dim1_g, dim2_g, g0, err) &
@@ -591,6 +600,33 @@ contains
     real(dp), intent(in) :: rad_enhancement
     call c_radtran_apply_radiation_enhancement(self%handle, rad_enhancement)
     call pull_results(self, .true.)
+  end subroutine
+
+  !> The RCE Jacobian's radiative calls in one go (src/adiabat/clima_adiabat_solve.f90:798-812):
+  !> column i is `radiate(T_surface(i), T(:,i), ..., compute_solar=.false., compute_opacity=.false.)`
+  !> on the opacities of the last compute_opacity call; `f_total(:,i)` is what that call would
+  !> leave in `self%f_total`, `fup_n`/`fdn_n` what it would leave in `self%wrk_ir`.
+  subroutine Radtran_radiate_ir_batch(self, T_surface, T, fup_n, fdn_n, f_total, err)
+    class(Radtran), intent(inout) :: self
+    real(dp), intent(in) :: T_surface(:)   !! (ncol)
+    real(dp), intent(in) :: T(:,:)         !! (nz, ncol)
+    real(dp), intent(out) :: fup_n(:,:), fdn_n(:,:), f_total(:,:)   !! (nz+1, ncol)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    real(dp), allocatable :: Tc(:,:), a(:,:), b(:,:), c(:,:)
+    integer :: ncol
+    ncol = size(T_surface)
+    if (size(T,2) /= ncol .or. any(shape(fup_n) /= [self%nz+1, ncol]) .or. &
+        any(shape(fdn_n) /= [self%nz+1, ncol]) .or. any(shape(f_total) /= [self%nz+1, ncol])) then
+      err = '"T" has the wrong input dimension.'
+      return
+    endif
+    Tc = T
+    allocate(a(self%nz+1,ncol), b(self%nz+1,ncol), c(self%nz+1,ncol))
+    call c_radtran_radiate_ir_batch(self%handle, ncol, T_surface, size(Tc,1), size(Tc,2), Tc, a, b, c, err_c)
+    call take_err(err_c, err)
+    if (allocated(err)) return
+    fup_n = a; fdn_n = b; f_total = c
   end subroutine
 
   !> clima_radtran.f90:494-506

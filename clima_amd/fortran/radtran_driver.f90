@@ -103,6 +103,15 @@ program radtran_driver
   write(u,'(es26.17e3)') rad%f_total
   write(u,'(es26.17e3)') rad%wrk_ir%fup_a(nz+1,:)   ! tests/test_radtran.f90:77
   write(u,'(es26.17e3)') rad%wrk_sol%fup_a(nz+1,:)  ! :79
+
+  ! the same pattern batched: three temperature columns (base, surface +1 K, layer 1 +1 K)
+  block
+    real(dp) :: Tsb(3), Tb(nz,3), bup(nz+1,3), bdn(nz+1,3), bft(nz+1,3)
+    Tsb = T_surface; Tsb(2) = T_surface + 1.0_dp
+    Tb(:,1) = T; Tb(:,2) = T; Tb(:,3) = T; Tb(1,3) = T(1) + 1.0_dp
+    call rad%radiate_ir_batch(Tsb, Tb, bup, bdn, bft, err); call check()
+    write(u,'(es26.17e3)') bft
+  end block
   close(u)
 
   ! error convention: allocated err <=> failure, reference message text

@@ -35,6 +35,7 @@ def test_fortran_driver_matches_python_and_oracle(O, tmp_path):
     f_total = vals[p:p + nz + 1]; p += nz + 1
     ir_toa = vals[p:p + nw_ir]; p += nw_ir
     sol_toa = vals[p:p + nw_sol]; p += nw_sol
+    batch_ft = vals[p:p + 3 * (nz + 1)].reshape(3, nz + 1).T; p += 3 * (nz + 1)
     assert p == len(vals)
     # printed quantity of tests/test_radtran.f90:73
     assert abs(float(out.stdout.split()[0]) - sol_fdn_n[nz] * 1e-3) < 1e-9 * abs(sol_fdn_n[nz] * 1e-3)
@@ -46,6 +47,13 @@ def test_fortran_driver_matches_python_and_oracle(O, tmp_path):
     assert np.array_equal(ir_fup_n, r.wrk_ir.fup_n) and np.array_equal(sol_fdn_n, r.wrk_sol.fdn_n)
     assert np.array_equal(f_total, r.f_total)
     assert np.array_equal(ir_toa, r.wrk_ir.fup_a[nz, :]) and np.array_equal(sol_toa, r.wrk_sol.fup_a[nz, :])
+
+    # type-bound radiate_ir_batch: base column, surface +1 K, lowest layer +1 K
+    Tb = np.repeat(np.asarray(col["T"])[:, None], 3, axis=1)
+    Tb[0, 2] += 1.0
+    Ts = np.array([col["T_surface"], col["T_surface"] + 1.0, col["T_surface"]])
+    _, _, ft = r.radiate_ir_batch(Ts, Tb)
+    assert np.array_equal(batch_ft, ft) and np.array_equal(ft[:, 0], r.f_total)
 
     o = O.OracleRadtran(tb, nz, nzen, albedo)
     isr_o, olr_o = o.TOA_fluxes(*col.args())
