@@ -1638,8 +1638,10 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 
 // one launch for both channels: blocks [0, n_sol) are solar bins (the heavier ones first),
 // blocks [n_sol, n_sol+n_ir) IR bins
+// LMAX = 8 would take 260 VGPRs (one wave per SIMD); capping it at 256 costs a few spills and buys
+// the second wave
 template <int LMAX>
-__global__ __launch_bounds__(64 * TSW_COLS) void k_twostream_w(TwoStreamParams p) {
+__global__ __launch_bounds__(64 * TSW_COLS, LMAX > 4 ? 2 : 1) void k_twostream_w(TwoStreamParams p) {
   extern __shared__ __align__(16) double lds[];  // [3][TSW_COLS][nz+1] weighted level values
   if ((int)blockIdx.x < p.n_sol) twostream_w_body<LMAX, true, false, 0>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
   else twostream_w_body<LMAX, false, false, 0>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
@@ -1753,11 +1755,15 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
 
 // false when the configuration is outside what the fused form covers (the caller then uses the
 // separate launches)
-bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s) {
+bool fused_supported(const OpacityParams &op, const TwoStreamParams &ts) {
   if (op.ng != 8 || (ts.nz + 63) / 64 > 4 || ts.nzen > MAX_ZEN) return false;
+  return (long)op.nbins * op.nz > 0 && ts.n_sol + ts.n_ir > 0;
+}
+
+bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s) {
+  if (!fused_supported(op, ts)) return false;
   const long total = (long)op.nbins * op.nz;
   const int nb = ts.n_sol + ts.n_ir;
-  if (total <= 0 || nb <= 0) return false;
   fp.n_op = (int)((total + OP_THREADS - 1) / OP_THREADS);
   const int groups = (ts.ng + TSW_COLS - 1) / TSW_COLS;  // 2
   ts.col_base = 0; ts.accumulate = 1;

@@ -458,10 +458,12 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     op.tau = r->d_tau.p; op.w0 = r->d_w0.p; op.g = r->d_g.p; op.tau_band = r->d_tau_band.p;
     if (r->fused && pre_zeroed) {
       TwoStreamParams tsf = make_twostream_params(r, col, compute_solar);
-      FusedParams fp{0, pp.call_id, 400000, r->d_done.p, r->d_err.p};
-      KernelTimer t(r, 1);
-      fused_done = launch_fused(op, tsf, fp, r->stream);
-      t.stop();
+      if (fused_supported(op, tsf)) {
+        FusedParams fp{0, pp.call_id, 400000, r->d_done.p, r->d_err.p};
+        KernelTimer t(r, 1);
+        fused_done = launch_fused(op, tsf, fp, r->stream);
+        t.stop();
+      }
     }
     if (!fused_done) {
       KernelTimer t(r, 1);

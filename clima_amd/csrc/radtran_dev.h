@@ -198,6 +198,7 @@ void launch_prep(const PrepParams &p, hipStream_t s);
 bool launch_opacity(const OpacityParams &p, hipStream_t s);
 bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
 bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed);
+bool fused_supported(const OpacityParams &op, const TwoStreamParams &ts);
 bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s);
 int twostream_w_groups(int ng);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
