@@ -173,7 +173,7 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         value = args.steps / dt
         names = list(KERNELS)
-        if rad.fused:   # opacity and two-stream work run as one grid (k_fused), timed as kernel id 1
+        if rad.fused and kt[2][1] == 0:   # opacity and two-stream work ran as one grid (k_fused), timed as kernel id 1
             names[1] = "fused"
         per_kernel_us = {k: (1e3 * ms / n if n else 0.0) for k, (ms, n) in zip(names, kt) if n}
         dom = max(per_kernel_us, key=per_kernel_us.get)
