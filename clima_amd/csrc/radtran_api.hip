@@ -268,16 +268,22 @@ void upload_fields(Radtran *r) {
   r->fields_dirty = false;
 }
 
+// relative cost of a bin's opacity work, IR solve, solar solve (base + per zenith angle)
+constexpr double SHARD_W_OP = 3.0, SHARD_W_IR = 1.0, SHARD_W_SOL0 = 0.6, SHARD_W_SOLZ = 0.24;
+
 void compute_shard(Radtran *r) {
-  // contiguous opacity-bin ranges balanced by work: opacity 1, IR solve 1, solar solve
-  // 1 + nzen/2; rank 0-based.
+  // contiguous opacity-bin ranges balanced by work: opacity 3, IR solve 1, solar
+  // solve 0.6 + 0.24 nzen -- the measured device-time ratios of the three kinds of work on MI355X
+  // (tools/gpu_balance.py); rank 0-based.
   const int nw = r->nw, W = r->shard_world, R = r->shard_rank;
   std::vector<double> cost(nw + 1, 0.0);
   const int nzen = (int)r->zenith_u.size();
+  double w_op = SHARD_W_OP, w_ir = SHARD_W_IR, w_s0 = SHARD_W_SOL0, w_sz = SHARD_W_SOLZ;
+  if (const char *e = getenv("CLIMA_HIP_SHARD_COST")) (void)sscanf(e, "%lf,%lf,%lf,%lf", &w_op, &w_ir, &w_s0, &w_sz);  // tuning aid
   for (int l = 0; l < nw; l++) {
-    double c = 1.0;
-    if (l >= r->ir.ind_start && l <= r->ir.ind_end) c += 1.0;
-    if (l >= r->sol.ind_start && l <= r->sol.ind_end) c += 1.0 + 0.5 * nzen;
+    double c = w_op;
+    if (l >= r->ir.ind_start && l <= r->ir.ind_end) c += w_ir;
+    if (l >= r->sol.ind_start && l <= r->sol.ind_end) c += w_s0 + w_sz * nzen;
     cost[l + 1] = cost[l] + c;
   }
   auto cut = [&](int k) {

@@ -11,17 +11,20 @@ This is the host-side statement of the rule implemented in csrc/radtran_api.hip
 """
 import bisect
 
+W_OPACITY, W_IR, W_SOLAR_BASE, W_SOLAR_PER_ZENITH = 3.0, 1.0, 0.6, 0.24
+
 
 def bin_costs(nw, ir_range, sol_range, nzen):
-    """Relative cost of every opacity bin: opacity 1, IR solve 1, solar solve 1 + nzen/2.
+    """Relative cost of every opacity bin: opacity 3, IR solve 1, solar solve 0.6 + 0.24 nzen
+    (measured device-time ratios on MI355X, tools/gpu_balance.py).
     ir_range / sol_range are (first, last) opacity-bin indices, inclusive, 0-based."""
     cost = []
     for l in range(nw):
-        c = 1.0
+        c = W_OPACITY
         if ir_range[0] <= l <= ir_range[1]:
-            c += 1.0
+            c += W_IR
         if sol_range[0] <= l <= sol_range[1]:
-            c += 1.0 + 0.5 * nzen
+            c += W_SOLAR_BASE + W_SOLAR_PER_ZENITH * nzen
         cost.append(c)
     return cost
 
