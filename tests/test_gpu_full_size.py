@@ -92,7 +92,7 @@ def test_bin_sharded_partials_add_up(nominal):
     covered = 0
     for rank in range(world):
         r.set_bin_shard(rank, world)
-        if not os.environ.get("CLIMA_HIP_SHARD_COST"): assert r.bin_shard() == bin_shard(tb.nw, (ir0, ir0 + nw_ir - 1), (0, nw_sol - 1), 8, rank, world)
+        assert r.bin_shard() == bin_shard(tb.nw, (ir0, ir0 + nw_ir - 1), (0, nw_sol - 1), 8, rank, world)
         covered += r.bin_shard()[1]
         r.upload_column(*col.args())
         r.radiate_resident()
