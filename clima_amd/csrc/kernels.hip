@@ -13,6 +13,7 @@
 //
 // All arithmetic is IEEE binary64.  No MFMA: there is no dense contraction on this path.
 #include "radtran_dev.h"
+#include <algorithm>
 
 namespace clima {
 
@@ -1698,6 +1699,355 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   return true;
 }
 
+
+
+// ------------------------------------------------------------------------------------
+// k_twostream_ir_batch: many temperature columns on ONE set of opacities (the RCE Jacobian's
+// radiative work, src/adiabat/clima_adiabat_solve.f90:798-812).  Everything in two_stream_ir
+// that does not depend on temperature -- gamma's, lambda, exp(-lambda tau), the elimination of
+// the tridiagonal system, the reflectances that join the lane chunks -- is done once per
+// (bin, g-point); a temperature column then costs only its Planck values (computed once per
+// bin and shared by the g-point waves through LDS), the linear source terms, the right-hand
+// side sweeps and two affine wave scans: ~200 instructions per lane instead of ~1700.
+//
+// Same decomposition as twostream_w_body (lane q owns layers [q nz/64, (q+1) nz/64), flux
+// boundary conditions per chunk); written as
+//     y_r = alpha_r + beta_r Uin + gamma_r Din            inside a chunk,
+//     sig_above_q = A_q + Bq sig_above_{q+1}              bottom-up (source seen from above),
+//     Din_{q+1}   = sa_q + sb_q Din_q                     top-down,
+// with beta, gamma, B, sb and the reflectances rho fixed by the opacities.
+// One block = the (up to) 8 g-point waves of one bin; it loops over its share of the columns.
+// ------------------------------------------------------------------------------------
+constexpr int IRB_WAVES = 8;   // g-point waves per block: the kernel covers ng <= 8
+constexpr int IRB_TILE = 8;    // columns whose Planck values sit in LDS together
+#ifndef IRB_NC
+#define IRB_NC 1               // columns a wave works on at once; 2 interleaves their dependent chains but spills
+                               // ~100 more registers and measured slower (13.5 vs 10.0 us per column)
+#endif
+
+template <int LMAX>
+__global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStreamParams p, int ncol, int cols_per_block) {
+  extern __shared__ __align__(16) double lds[];
+  const int nz = p.nz, ng = p.ng, nl = nz + 1;
+  double *sB = lds;                          // [IRB_TILE][nl] Planck, TOA-first levels
+  double *sF0 = lds + (size_t)IRB_TILE * nl;  // [2 columns][2][IRB_WAVES][nl] weighted level fluxes
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ll = p.ir_lo + (int)blockIdx.x;
+  const int l = p.ir_start + ll;
+  const bool col_on = wave < ng;
+  const int cg = col_on ? wave : ng - 1;
+  const double wcol = col_on ? p.wbin[cg] : 0.0;
+  const double *tauL = p.tau + ((size_t)l * ng + cg) * nz;
+  const double *w0L = p.w0 + ((size_t)l * ng + cg) * nz;
+  const double *gL = p.g + (size_t)l * nz;
+  const int a = (lane * nz) >> 6, b = ((lane + 1) * nz) >> 6, len = b - a;
+  const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);
+  const bool hard = p.has_hard_surface != 0;
+  const double emis = hard ? p.emissivity[ll] : 0.0;
+  const double Rsfc = hard ? 1.0 - emis : 0.0;  // twostream.f90:186-190
+
+  // ---- temperature-independent part -------------------------------------------------
+  double G[LMAX], X[LMAX], itau[LMAX], rq[LMAX], tauv[LMAX];
+  double rr[2 * LMAX], ar[2 * LMAX], cc[2 * LMAX], be[2 * LMAX], ga[2 * LMAX];
+  {
+    double cp = 0.0, lp = -1.0;
+    E4 u = make_e(0.0, 0.0);
+#pragma unroll
+    for (int t = 0; t < LMAX; t++) {
+      G[t] = X[t] = itau[t] = rq[t] = tauv[t] = 0.0;
+      rr[2 * t] = rr[2 * t + 1] = ar[2 * t] = ar[2 * t + 1] = cc[2 * t] = cc[2 * t + 1] = 0.0;
+      be[2 * t] = be[2 * t + 1] = ga[2 * t] = ga[2 * t + 1] = 0.0;
+      if (t < len) {
+        const int i = a + t;
+        const double tau_in = tauL[i], w0_in = w0L[i], gt_in = gL[i];
+        const double gam1 = 2.0 - w0_in * (1.0 + gt_in);  // :195-201
+        const double gam2 = w0_in * (1.0 - gt_in);
+        const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
+        G[t] = gam2 / (gam1 + lam);
+        X[t] = fast_exp(-lam * tau_in);
+        itau[t] = (tau_in <= p.ir_tau_min) ? 0.0 : 1.0 / tau_in;  // 0 marks the thin-layer source rule (:216-227)
+        rq[t] = 1.0 / (gam1 + gam2);
+        tauv[t] = tau_in;
+        const E4 v = make_e(G[t], X[t]);
+        if (t == 0) {
+          const double A = (a == 0) ? 0.0 : -1.0;
+          const double r = rcp_nr(v.e1 - A * cp);
+          rr[0] = r; ar[0] = A * r;
+          cp = (-v.e2) * r; lp = (-A * lp) * r;
+          cc[0] = cp; ga[0] = lp;
+        } else {
+          double A = v.e2 * u.e1 - u.e3 * v.e4, B = u.e2 * v.e2 - u.e4 * v.e4, D = v.e1 * v.e4 - v.e2 * v.e3;
+          double r = rcp_nr(B - A * cp);
+          rr[2 * t - 1] = r; ar[2 * t - 1] = A * r;
+          const double cn = D * r, ln = (-A * lp) * r;
+          cc[2 * t - 1] = cn; ga[2 * t - 1] = ln;
+          A = u.e2 * u.e3 - u.e4 * u.e1; B = u.e1 * v.e1 - u.e3 * v.e3; D = u.e3 * v.e4 - u.e1 * v.e2;
+          r = rcp_nr(B - A * cn);
+          rr[2 * t] = r; ar[2 * t] = A * r;
+          cp = D * r; lp = (-A * ln) * r;
+          cc[2 * t] = cp; ga[2 * t] = lp;
+        }
+        if (t == len - 1) {
+          double A, B, D;
+          if (b == nz) { A = v.e1 - Rsfc * v.e3; B = v.e2 - Rsfc * v.e4; D = 0.0; }
+          else { A = v.e1; B = v.e2; D = -1.0; }
+          const double r = rcp_nr(B - A * cp);
+          rr[2 * t + 1] = r; ar[2 * t + 1] = A * r;
+          cc[2 * t + 1] = D * r; ga[2 * t + 1] = (-A * lp) * r;
+        }
+        u = v;
+      }
+    }
+  }
+  // upward sweep of the Uin / Din coefficients (ga holds the l_r of the downward pass on entry)
+  double bB0 = 0, gB0 = 0, bB1 = 0, gB1 = 0;
+  {
+    double bev = 1.0, gav = 0.0;
+#pragma unroll
+    for (int r = 2 * LMAX - 1; r >= 0; r--) {
+      if (r < 2 * len) {
+        const double c_ = cc[r], lc = ga[r];
+        bev = -c_ * bev; gav = -lc - c_ * gav;
+        be[r] = bev; ga[r] = gav;
+        if (r == 2 * len - 1) { bB1 = bev; gB1 = gav; }
+        if (r == 2 * len - 2) { bB0 = bev; gB0 = gav; }
+      }
+    }
+  }
+  // the chunk as a map of (Din, Uin): temperature-independent entries
+  double uD = 0.0, uU = 1.0, dD = 1.0, dU = 0.0;
+  double ea3 = 0.0, ea4 = 0.0, eb3 = 0.0, eb4 = 0.0;
+  if (len > 0) {
+    const E4 ea = make_e(G[0], X[0]);
+    double Gb = G[0], Xb = X[0];
+#pragma unroll
+    for (int t = 1; t < LMAX; t++)
+      if (t == len - 1) { Gb = G[t]; Xb = X[t]; }
+    const E4 eb = make_e(Gb, Xb);
+    ea3 = ea.e3; ea4 = ea.e4; eb3 = eb.e3; eb4 = eb.e4;
+    uD = ga[0] * ea3 - ga[1] * ea4; uU = be[0] * ea3 - be[1] * ea4;
+    dD = gB0 * eb3 + gB1 * eb4; dU = bB0 * eb3 + bB1 * eb4;
+  }
+  // reflectance seen from above every interface: projective suffix scan of 2x2 matrices
+  double rho;
+  {
+    double m00 = uU * dD - uD * dU, m02 = uD, m20 = -dU, m22 = 1.0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double r00 = __shfl_down(m00, d), r02 = __shfl_down(m02, d), r20 = __shfl_down(m20, d), r22 = __shfl_down(m22, d);
+      if (lane + d < 64) {
+        const double n00 = m00 * r00 + m02 * r20, n02 = m00 * r02 + m02 * r22;
+        const double n20 = m20 * r00 + m22 * r20, n22 = m20 * r02 + m22 * r22;
+        m00 = n00; m02 = n02; m20 = n20; m22 = n22;
+      }
+    }
+    const double rho_above = m02 * rcp_nr(m22);
+    rho = __shfl_down(rho_above, 1);
+    if (lane == 63) rho = 0.0;
+  }
+  const double mm = rcp_nr(1.0 - rho * dU);
+  // scan coefficients: sig_above_q = A_q + Bq*sig_above_{q+1};  Din_{q+1} = sa_q + sb_q*Din_q
+  // (kept in LDS, one slot per thread and step: they are read once per column and would otherwise
+  // cost 24 VGPRs of a budget that is already spilling)
+  double *sStep = sF0 + (size_t)4 * IRB_WAVES * nl + threadIdx.x;  // [12][blockDim.x]
+  {
+    double bq = uU * mm, sb = dD * (1.0 + dU * mm * rho);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int d = 1 << k;
+      sStep[(size_t)k * blockDim.x] = (lane + d < 64) ? bq : 0.0;     // 0: no partner, the term drops out
+      const double pb = __shfl_down(bq, d);
+      if (lane + d < 64) bq = bq * pb;
+      sStep[(size_t)(6 + k) * blockDim.x] = (lane >= d) ? sb : 0.0;
+      const double qb = __shfl_up(sb, d);
+      if (lane >= d) sb = sb * qb;
+    }
+  }
+  const double kA = uU * mm * rho;   // A_q = uS + kA*dS
+  const double kS = dU * mm;         // sa_q = dS + kS*(rho*dS + sig)
+
+  // ---- the columns ---------------------------------------------------------------------
+  const int c_begin = (int)blockIdx.z * cols_per_block;
+  const int c_end = min(ncol, c_begin + cols_per_block);
+  for (int c0 = c_begin; c0 < c_end; c0 += IRB_TILE) {
+    const int nt = min(IRB_TILE, c_end - c0);
+    __syncthreads();  // the previous tile's Planck values are no longer read
+    for (int idx = threadIdx.x; idx < nt * nl; idx += blockDim.x) {
+      const int cj = idx / nl, n = idx - cj * nl;
+      const double *Tc = p.T + (size_t)(c0 + cj) * p.b_T;
+      const double temp = (n == nz) ? p.T_surface[(size_t)(c0 + cj) * p.b_Ts] : Tc[nz - 1 - n];  // radiate.f90:65-69
+      sB[(size_t)cj * nl + n] = planck_fcn(avg_freq, temp);
+    }
+    __syncthreads();
+    // IRB_NC columns at a time: their dependent chains (sweeps, two 6-step wave scans) interleave
+    for (int cj0 = 0; cj0 < nt; cj0 += IRB_NC) {
+      const double *Bc[IRB_NC];
+      double dd[IRB_NC][2 * LMAX];
+      double cp0_top[IRB_NC], cmb_last[IRB_NC], uS[IRB_NC], dS[IRB_NC], Uin[IRB_NC], Din[IRB_NC];
+#pragma unroll
+      for (int q = 0; q < IRB_NC; q++) {
+        Bc[q] = sB + (size_t)min(cj0 + q, nt - 1) * nl;   // an odd tail repeats the last column (not stored)
+        cp0_top[q] = 0.0; cmb_last[q] = 0.0;
+        double dpv = 0.0, cpb_u = 0.0, cmb_u = 0.0;
+        E4 u = make_e(0.0, 0.0);
+        double Bt = (len > 0) ? Bc[q][a] : 0.0;
+#pragma unroll
+        for (int t = 0; t < LMAX; t++) {
+          dd[q][2 * t] = dd[q][2 * t + 1] = 0.0;
+          if (t < len) {
+            const double Bb = Bc[q][a + t + 1];
+            const bool thin = itau[t] == 0.0;
+            const double b1n = (Bb - Bt) * itau[t];               // :216-227
+            const double b0n = thin ? 0.5 * (Bt + Bb) : Bt;
+            const double cp0 = PI * (b0n + b1n * rq[t]);          // :229-232, norm = 2 pi * 1/2
+            const double cpbv = PI * (b0n + b1n * (tauv[t] + rq[t]));
+            const double cm0 = PI * (b0n - b1n * rq[t]);
+            const double cmbv = PI * (b0n + b1n * (tauv[t] - rq[t]));
+            const E4 v = make_e(G[t], X[t]);
+            if (t == 0) {
+              cp0_top[q] = cp0;
+              dpv = (0.0 - cm0) * rr[0];
+              dd[q][0] = dpv;
+            } else {
+              const double E1 = v.e2 * (cp0 - cpb_u) - v.e4 * (cm0 - cmb_u);
+              const double dn = E1 * rr[2 * t - 1] - ar[2 * t - 1] * dpv;
+              dd[q][2 * t - 1] = dn;
+              const double E2 = u.e3 * (cp0 - cpb_u) + u.e1 * (cmb_u - cm0);
+              dpv = E2 * rr[2 * t] - ar[2 * t] * dn;
+              dd[q][2 * t] = dpv;
+            }
+            if (t == len - 1) {
+              double E;
+              if (b == nz) {  // surface row (:236-247)
+                const double Ssfc = hard ? emis * PI * Bb : PI * (Bb + 0.5 * b1n);
+                E = Ssfc - cpbv + Rsfc * cmbv;
+              } else {
+                E = 0.0 - cpbv;
+              }
+              dd[q][2 * t + 1] = E * rr[2 * t + 1] - ar[2 * t + 1] * dpv;
+              cmb_last[q] = cmbv;
+            }
+            u = v; cpb_u = cpbv; cmb_u = cmbv; Bt = Bb;
+          }
+        }
+        // upward: alpha_r (overwrites dd)
+        double aB0 = 0.0, aB1 = 0.0, al = 0.0;
+#pragma unroll
+        for (int r = 2 * LMAX - 1; r >= 0; r--) {
+          if (r < 2 * len) {
+            al = dd[q][r] - cc[r] * al;
+            dd[q][r] = al;
+            if (r == 2 * len - 1) aB1 = al;
+            if (r == 2 * len - 2) aB0 = al;
+          }
+        }
+        uS[q] = 0.0; dS[q] = 0.0;
+        if (len > 0) {
+          uS[q] = dd[q][0] * ea3 - dd[q][1] * ea4 + cp0_top[q];
+          dS[q] = aB0 * eb3 + aB1 * eb4 + cmb_last[q];
+        }
+      }
+      // bottom-up: source seen from above each interface
+      double sg[IRB_NC], sa[IRB_NC];
+#pragma unroll
+      for (int q = 0; q < IRB_NC; q++) sg[q] = uS[q] + kA * dS[q];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const double bs = sStep[(size_t)k * blockDim.x];
+#pragma unroll
+        for (int q = 0; q < IRB_NC; q++) sg[q] = sg[q] + bs * __shfl_down(sg[q], 1 << k);
+      }
+      // top-down: diffuse flux entering each chunk from above
+#pragma unroll
+      for (int q = 0; q < IRB_NC; q++) {
+        double sig = __shfl_down(sg[q], 1);
+        if (lane == 63) sig = 0.0;
+        sg[q] = sig;
+        sa[q] = dS[q] + kS * (rho * dS[q] + sig);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const double ss = sStep[(size_t)(6 + k) * blockDim.x];
+#pragma unroll
+        for (int q = 0; q < IRB_NC; q++) sa[q] = sa[q] + ss * __shfl_up(sa[q], 1 << k);
+      }
+#pragma unroll
+      for (int q = 0; q < IRB_NC; q++) {
+        double d_in = __shfl_up(sa[q], 1);
+        if (lane == 0) d_in = 0.0;
+        Din[q] = d_in;
+        Uin[q] = mm * (rho * dS[q] + sg[q] + rho * dD * d_in);
+      }
+      // level fluxes (:288-293), g-point weight; column q of the group goes to staging buffer q
+#pragma unroll
+      for (int q = 0; q < IRB_NC; q++) {
+        const int buf = (IRB_NC == 1) ? (cj0 & 1) : q;   // one column at a time: alternate the two buffers
+        double *sFu = sF0 + (size_t)buf * 2 * IRB_WAVES * nl + (size_t)(0 * IRB_WAVES + wave) * nl;
+        double *sFd = sF0 + (size_t)buf * 2 * IRB_WAVES * nl + (size_t)(1 * IRB_WAVES + wave) * nl;
+#pragma unroll
+        for (int t = 0; t < LMAX; t++) {
+          if (t < len) {
+            const int i = a + t;
+            const E4 e = make_e(G[t], X[t]);
+            const double y1 = dd[q][2 * t] + be[2 * t] * Uin[q] + ga[2 * t] * Din[q];
+            const double y2 = dd[q][2 * t + 1] + be[2 * t + 1] * Uin[q] + ga[2 * t + 1] * Din[q];
+            // the layer-bottom source terms again (cheaper than keeping them across the scans)
+            const double Bt2 = Bc[q][i], Bb2 = Bc[q][i + 1];
+            const double b1n = (Bb2 - Bt2) * itau[t];
+            const double b0n = (itau[t] == 0.0) ? 0.5 * (Bt2 + Bb2) : Bt2;
+            const double cpbv = PI * (b0n + b1n * (tauv[t] + rq[t]));
+            const double cmbv = PI * (b0n + b1n * (tauv[t] - rq[t]));
+            sFu[i + 1] = wcol * (y1 * e.e1 + y2 * e.e2 + cpbv);
+            sFd[i + 1] = wcol * (y1 * e.e3 + y2 * e.e4 + cmbv);
+            if (i == 0) {
+              sFu[0] = wcol * ((y1 * e.e3 - y2 * e.e4) + cp0_top[q]);
+              sFd[0] = 0.0;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // sum over the g-points (in g order), reversal to ground-first (radiate.f90:140-154)
+      for (int idx = threadIdx.x; idx < IRB_NC * nl; idx += blockDim.x) {
+        const int q = idx / nl, n = idx - q * nl;
+        if (cj0 + q < nt) {
+          const double *sF = sF0 + (size_t)((IRB_NC == 1) ? (cj0 & 1) : q) * 2 * IRB_WAVES * nl;
+          double fu = 0.0, fd = 0.0;
+#pragma unroll
+          for (int w = 0; w < IRB_WAVES; w++) {
+            fu = fu + sF[(size_t)(0 * IRB_WAVES + w) * nl + n];
+            fd = fd + sF[(size_t)(1 * IRB_WAVES + w) * nl + n];
+          }
+          const size_t o = (size_t)(c0 + cj0 + q) * p.b_out + (size_t)ll * nl + (nz - n);
+          p.ir_fup_a[o] = fu;
+          p.ir_fdn_a[o] = fd;
+        }
+      }
+      if (IRB_NC > 1) __syncthreads();  // the staging buffers are free again (alternated when IRB_NC == 1)
+    }
+  }
+}
+
+// false when the configuration is outside what the kernel covers: more than 8 g-points, or more
+// than 4 layers per lane (nz > 256) -- the 8-layer instantiation spills ~500 registers and is
+// slower than one full solve per column (measured at nz = 500: 97 vs 37 us per column)
+bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s) {
+  const int lmax = (p.nz + 63) / 64;
+  if (p.ng > IRB_WAVES || lmax > 4 || p.n_ir <= 0 || ncol <= 0) return false;
+  const size_t lds = sizeof(double) * ((size_t)(IRB_TILE + 4 * IRB_WAVES) * ((size_t)p.nz + 1) + 12 * 64 * IRB_WAVES);
+  if (lds > 160 * 1024) return false;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)k_twostream_ir_batch<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  // enough blocks to fill the chip a few times over, each with a worthwhile run of columns
+  int cpb = (ncol + 3) / 4;
+  if (cpb < IRB_TILE) cpb = std::min(ncol, IRB_TILE);
+  const dim3 grid(p.n_ir, 1, (ncol + cpb - 1) / cpb), blk(64 * IRB_WAVES);
+  hipLaunchKernelGGL((k_twostream_ir_batch<4>), grid, blk, lds, s, p, ncol, cpb);
+  return true;
+}
 
 // ------------------------------------------------------------------------------------
 // k_fused: opacity and two-stream work of one call in ONE grid.  Blocks [0, n_op) are the

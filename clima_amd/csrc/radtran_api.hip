@@ -159,6 +159,7 @@ struct Radtran {
   int op_lo = 0, op_n = 0, ir_lo = 0, ir_n = 0, sol_lo = 0, sol_n = 0;
   // stream + profiling
   hipStream_t stream = nullptr;
+  bool batch_shared = true;        // radiate_ir_batch: temperature-independent work shared by the columns (CLIMA_HIP_BATCH_SHARED=0: one full solve per column)
   bool fused = true;               // opacity + two-stream in one grid (k_fused); CLIMA_HIP_FUSED=0 or radtran_fused_set turns it off
   DevBuf<int> d_done;              // per opacity block: call id of its last completed run
   int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (k_opacity) only
@@ -818,6 +819,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   if (dev_count < 1) throw HipFail{"no HIP device available: the Radtran hot path has no CPU fallback"};
   HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
   if (const char *f = getenv("CLIMA_HIP_FUSED")) r->fused = atoi(f) != 0;
+  if (const char *f = getenv("CLIMA_HIP_BATCH_SHARED")) r->batch_shared = atoi(f) != 0;
 
   // ---- tables to HBM + interpolation slots
   r->slots.clear();
@@ -973,14 +975,17 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   const bool split = twostream_w_groups(r->ng) > 1;
   for (int c0 = 0; c0 < n; c0 += CH) {
     const int nc = std::min(CH, n - c0);
-    if (split) {  // g-point groups add into zeroed spectra
-      HIPCHK(hipMemsetAsync(r->d_bup.p, 0, sizeof(double) * spec * nc, r->stream));
-      HIPCHK(hipMemsetAsync(r->d_bdn.p, 0, sizeof(double) * spec * nc, r->stream));
-    }
     TwoStreamParams tb = ts;
     tb.T = r->d_bT.p + (size_t)c0 * nz; tb.T_surface = r->d_bTs.p + c0; tb.b_ncol = nc;
-    if (!launch_twostream_w(tb, r->stream, &r->ts_lds, true))
-      throw HipFail{"radiate_ir_batch: nz = " + std::to_string(nz) + " exceeds what the wave two-stream kernel holds (512)"};
+    // shared-matrix batch kernel (ng <= 8); otherwise one full solve per column
+    if (!(r->batch_shared && launch_twostream_ir_batch(tb, nc, r->stream))) {
+      if (split) {  // g-point groups add into zeroed spectra
+        HIPCHK(hipMemsetAsync(r->d_bup.p, 0, sizeof(double) * spec * nc, r->stream));
+        HIPCHK(hipMemsetAsync(r->d_bdn.p, 0, sizeof(double) * spec * nc, r->stream));
+      }
+      if (!launch_twostream_w(tb, r->stream, &r->ts_lds, true))
+        throw HipFail{"radiate_ir_batch: nz = " + std::to_string(nz) + " exceeds what the wave two-stream kernel holds (512)"};
+    }
     BatchIntegrateParams bp;
     std::memset(&bp, 0, sizeof(bp));
     bp.nz = nz; bp.ir_lo = r->ir_lo; bp.ir_n = r->ir_n; bp.nchunk = nchunk; bp.col0 = c0;

@@ -198,6 +198,8 @@ void launch_prep(const PrepParams &p, hipStream_t s);
 bool launch_opacity(const OpacityParams &p, hipStream_t s);
 bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
 bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed);
+// T + c*b_T, T_surface + c*b_Ts, IR spectra + c*b_out for column c of ncol
+bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s);
 bool fused_supported(const OpacityParams &op, const TwoStreamParams &ts);
 bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s);
 int twostream_w_groups(int ng);

@@ -53,7 +53,8 @@ def test_fortran_driver_matches_python_and_oracle(O, tmp_path):
     Tb[0, 2] += 1.0
     Ts = np.array([col["T_surface"], col["T_surface"] + 1.0, col["T_surface"]])
     _, _, ft = r.radiate_ir_batch(Ts, Tb)
-    assert np.array_equal(batch_ft, ft) and np.array_equal(ft[:, 0], r.f_total)
+    assert np.array_equal(batch_ft, ft)                         # Fortran and Python reach the same kernel
+    np.testing.assert_allclose(ft[:, 0], np.array(r.f_total), rtol=1e-11, atol=1e-11 * np.max(np.abs(ft)))
 
     o = O.OracleRadtran(tb, nz, nzen, albedo)
     isr_o, olr_o = o.TOA_fluxes(*col.args())
