@@ -162,7 +162,9 @@ struct Radtran {
   bool batch_shared = true;        // radiate_ir_batch: temperature-independent work shared by the columns (CLIMA_HIP_BATCH_SHARED=0: one full solve per column)
   bool fused = true;               // opacity + two-stream in one grid (k_fused); CLIMA_HIP_FUSED=0 or radtran_fused_set turns it off
   DevBuf<int> d_done;              // per opacity block: call id of its last completed run
-  int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (k_opacity) only
+  int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (id 1) only
+  long timer_calls = 0;
+  int profile_stride = 1;   // events on every profile_stride-th call only (bounds the cost of measuring)
   struct Ev { hipEvent_t a, b; int id; };
   std::vector<Ev> pending;
   std::vector<hipEvent_t> pool;
@@ -320,7 +322,10 @@ struct KernelTimer {
   Radtran *r;
   int id;
   hipEvent_t a = nullptr, b = nullptr;
-  bool on() const { return r->profile == 1 || (r->profile == 2 && id == 1); }
+  bool on() const {
+    if (r->profile_stride > 1 && (r->timer_calls % r->profile_stride) != 0) return false;
+    return r->profile == 1 || (r->profile == 2 && id == 1);
+  }
   KernelTimer(Radtran *r_, int id_) : r(r_), id(id_) {
     if (on()) {
       a = get_event(r);
@@ -398,6 +403,7 @@ TwoStreamParams make_twostream_params(Radtran *r, const ColumnDev &col, bool com
 }
 
 void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
+  r->timer_calls++;
   upload_fields(r);
   const int nz = r->nz;
   ColumnDev col = column_dev(r);
@@ -1119,6 +1125,10 @@ void radtran_stream_get(void *ptr, void **stream) {
 void radtran_profile_set(void *ptr, const int *enable) {
   Radtran *r = as_rad(ptr);
   if (r) r->profile = (*enable == 2) ? 2 : (*enable != 0 ? 1 : 0);
+}
+void radtran_profile_stride_set(void *ptr, const int *stride) {
+  Radtran *r = as_rad(ptr);
+  if (r) r->profile_stride = std::max(1, *stride);
 }
 void radtran_profile_reset(void *ptr) {
   Radtran *r = as_rad(ptr);

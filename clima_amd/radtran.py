@@ -315,6 +315,10 @@ class Radtran:
         kernel (k_opacity) only (two event records per call instead of eight), False/0 off."""
         self._L.radtran_profile_set(self._ptr, _i(2 if enable == 2 and enable is not True else (1 if enable else 0)))
 
+    def profile_stride(self, stride):
+        """Events on every `stride`-th call only."""
+        self._L.radtran_profile_stride_set(self._ptr, _i(int(stride)))
+
     def profile_reset(self):
         self._L.radtran_profile_reset(self._ptr)
 

@@ -153,6 +153,9 @@ void radtran_stream_get(void *ptr, void **stream);
  * them off; kernel_time_get returns accumulated ms and launch count for kernel id
  * (0 prep, 1 opacity, 2 twostream, 3 integrate) and resets nothing. */
 void radtran_profile_set(void *ptr, const int *enable);
+/* record the events on every stride-th call only (default 1): an event pair drains the queue for a
+ * few microseconds, which a throughput measurement should not pay on every call */
+void radtran_profile_stride_set(void *ptr, const int *stride);
 void radtran_kernel_time_get(void *ptr, const int *kernel_id, double *ms_total, int *launches,
                              char *err);
 void radtran_profile_reset(void *ptr);
