@@ -1701,6 +1701,90 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
 
 
 
+
+// ------------------------------------------------------------------------------------
+// Wave-wide affine scans over DPP (data-parallel primitives) instead of ds_bpermute shuffles.
+// x_i = a_i + b_i * x_{i-1} over the 64 lanes, as composition of the maps (a_i, b_i); the
+// schedule is the row_shr 1,2,3 / 4 / 8 / row_bcast 15 / row_bcast 31 sequence (7 steps, each a
+// DPP move of the two halves of a double: a few cycles, where a ds_bpermute round trip is ~100).
+// A lane with no source in a step keeps `old`: 0 for an a-part, 1 for a b-part, which makes the
+// step the identity for it -- no participation masks needed.
+// ------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov(double old, double src) {
+  const long long o = __double_as_longlong(old), v = __double_as_longlong(src);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(v >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+constexpr int WSCAN_STEPS = 7;
+
+// value a step brings in from the lower lane(s); `orig` is the value before the scan (steps 0-2
+// read the original neighbours), `cur` the running one
+template <int STEP>
+__device__ __forceinline__ double wscan_fetch(double old, double orig, double cur) {
+  if constexpr (STEP == 0) return dpp_mov<DPP_ROW_SHR + 1, 0xf, 0xf>(old, orig);
+  else if constexpr (STEP == 1) return dpp_mov<DPP_ROW_SHR + 2, 0xf, 0xf>(old, orig);
+  else if constexpr (STEP == 2) return dpp_mov<DPP_ROW_SHR + 3, 0xf, 0xf>(old, orig);
+  else if constexpr (STEP == 3) return dpp_mov<DPP_ROW_SHR + 4, 0xf, 0xe>(old, cur);
+  else if constexpr (STEP == 4) return dpp_mov<DPP_ROW_SHR + 8, 0xf, 0xc>(old, cur);
+  else if constexpr (STEP == 5) return dpp_mov<DPP_ROW_BCAST15, 0xa, 0xf>(old, cur);
+  else return dpp_mov<DPP_ROW_BCAST31, 0xc, 0xf>(old, cur);
+}
+
+// Full scan of (a, b); bstep[k] receives the multiplier lane i applies in step k, so that later
+// scans with the same b's but other a's only need wscan_apply.
+template <int STEP>
+__device__ __forceinline__ void wscan_build_step(double &a, double &b, const double a0, const double b0, double *bstep) {
+  const double ta = wscan_fetch<STEP>(0.0, a0, a);
+  const double tb = wscan_fetch<STEP>(1.0, b0, b);
+  bstep[STEP] = b;
+  a = a + b * ta;
+  b = b * tb;
+}
+__device__ __forceinline__ void wscan_build(double &a, double &b, double *bstep) {
+  const double a0 = a, b0 = b;
+  wscan_build_step<0>(a, b, a0, b0, bstep); wscan_build_step<1>(a, b, a0, b0, bstep);
+  wscan_build_step<2>(a, b, a0, b0, bstep); wscan_build_step<3>(a, b, a0, b0, bstep);
+  wscan_build_step<4>(a, b, a0, b0, bstep); wscan_build_step<5>(a, b, a0, b0, bstep);
+  wscan_build_step<6>(a, b, a0, b0, bstep);
+}
+// a-part only, with the multipliers of a previous wscan_build (read through `bs(k)`)
+template <class BS>
+__device__ __forceinline__ double wscan_apply(double a, BS bs) {
+  const double a0 = a;
+  a = a + bs(0) * wscan_fetch<0>(0.0, a0, a);
+  a = a + bs(1) * wscan_fetch<1>(0.0, a0, a);
+  a = a + bs(2) * wscan_fetch<2>(0.0, a0, a);
+  a = a + bs(3) * wscan_fetch<3>(0.0, a0, a);
+  a = a + bs(4) * wscan_fetch<4>(0.0, a0, a);
+  a = a + bs(5) * wscan_fetch<5>(0.0, a0, a);
+  a = a + bs(6) * wscan_fetch<6>(0.0, a0, a);
+  return a;
+}
+// x[lane-1], 0 in lane 0
+__device__ __forceinline__ double wave_shr1(double x) { return dpp_mov<DPP_WAVE_SHR1, 0xf, 0xf>(0.0, x); }
+// x[63-lane]
+__device__ __forceinline__ double wave_reverse(double x) { return __shfl(x, 63 - (int)(threadIdx.x & 63)); }
+
+__global__ void k_test_wscan(const double *a, const double *b, double *out, int nwaves) {
+  // out[0]: inclusive affine scan x_i = a_i + b_i x_{i-1}; out[1]: the same through build + apply;
+  // out[2]: x shifted up by one lane; out[3]: reversed
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nwaves * 64) return;
+  const size_t n = (size_t)nwaves * 64;
+  double x = a[i], y = b[i], bstep[WSCAN_STEPS];
+  wscan_build(x, y, bstep);
+  out[i] = x;
+  out[n + i] = wscan_apply(a[i], [&](int k) { return bstep[k]; });
+  out[2 * n + i] = wave_shr1(a[i]);
+  out[3 * n + i] = wave_reverse(a[i]);
+}
+void launch_test_wscan(const double *a, const double *b, double *out, int nwaves, hipStream_t s) {
+  hipLaunchKernelGGL(k_test_wscan, dim3(nwaves), dim3(64), 0, s, a, b, out, nwaves);
+}
+
 // ------------------------------------------------------------------------------------
 // k_twostream_ir_batch: many temperature columns on ONE set of opacities (the RCE Jacobian's
 // radiative work, src/adiabat/clima_adiabat_solve.f90:798-812).  Everything in two_stream_ir
@@ -1847,21 +1931,21 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
   }
   const double mm = rcp_nr(1.0 - rho * dU);
   // scan coefficients: sig_above_q = A_q + Bq*sig_above_{q+1};  Din_{q+1} = sa_q + sb_q*Din_q
-  // (kept in LDS, one slot per thread and step: they are read once per column and would otherwise
-  // cost 24 VGPRs of a budget that is already spilling)
-  double *sStep = sF0 + (size_t)4 * IRB_WAVES * nl + threadIdx.x;  // [12][blockDim.x]
+  // Both scans run over DPP (wscan_*); the bottom-up one is a prefix scan of the lane-reversed
+  // data.  Their per-step multipliers live in LDS, one slot per thread and step: they are read
+  // once per column and would otherwise cost 28 VGPRs of a budget that is already spilling.
+  double *sStep = sF0 + (size_t)4 * IRB_WAVES * nl + threadIdx.x;  // [2 * WSCAN_STEPS][blockDim.x]
   {
-    double bq = uU * mm, sb = dD * (1.0 + dU * mm * rho);
+    double st[WSCAN_STEPS];
+    double dummy = 0.0, bq = wave_reverse(uU * mm);
+    wscan_build(dummy, bq, st);
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const int d = 1 << k;
-      sStep[(size_t)k * blockDim.x] = (lane + d < 64) ? bq : 0.0;     // 0: no partner, the term drops out
-      const double pb = __shfl_down(bq, d);
-      if (lane + d < 64) bq = bq * pb;
-      sStep[(size_t)(6 + k) * blockDim.x] = (lane >= d) ? sb : 0.0;
-      const double qb = __shfl_up(sb, d);
-      if (lane >= d) sb = sb * qb;
-    }
+    for (int k = 0; k < WSCAN_STEPS; k++) sStep[(size_t)k * blockDim.x] = st[k];
+    double sb = dD * (1.0 + dU * mm * rho);
+    dummy = 0.0;
+    wscan_build(dummy, sb, st);
+#pragma unroll
+    for (int k = 0; k < WSCAN_STEPS; k++) sStep[(size_t)(WSCAN_STEPS + k) * blockDim.x] = st[k];
   }
   const double kA = uU * mm * rho;   // A_q = uS + kA*dS
   const double kS = dU * mm;         // sa_q = dS + kS*(rho*dS + sig)
@@ -1947,36 +2031,17 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
           dS[q] = aB0 * eb3 + aB1 * eb4 + cmb_last[q];
         }
       }
-      // bottom-up: source seen from above each interface
-      double sg[IRB_NC], sa[IRB_NC];
-#pragma unroll
-      for (int q = 0; q < IRB_NC; q++) sg[q] = uS[q] + kA * dS[q];
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const double bs = sStep[(size_t)k * blockDim.x];
-#pragma unroll
-        for (int q = 0; q < IRB_NC; q++) sg[q] = sg[q] + bs * __shfl_down(sg[q], 1 << k);
-      }
-      // top-down: diffuse flux entering each chunk from above
+      // bottom-up: source seen from above each interface (prefix scan in lane-reversed order),
+      // then top-down: diffuse flux entering each chunk from above
 #pragma unroll
       for (int q = 0; q < IRB_NC; q++) {
-        double sig = __shfl_down(sg[q], 1);
-        if (lane == 63) sig = 0.0;
-        sg[q] = sig;
-        sa[q] = dS[q] + kS * (rho * dS[q] + sig);
-      }
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const double ss = sStep[(size_t)(6 + k) * blockDim.x];
-#pragma unroll
-        for (int q = 0; q < IRB_NC; q++) sa[q] = sa[q] + ss * __shfl_up(sa[q], 1 << k);
-      }
-#pragma unroll
-      for (int q = 0; q < IRB_NC; q++) {
-        double d_in = __shfl_up(sa[q], 1);
-        if (lane == 0) d_in = 0.0;
+        const double sgr = wscan_apply(wave_reverse(uS[q] + kA * dS[q]), [&](int k) { return sStep[(size_t)k * blockDim.x]; });
+        const double sig = wave_reverse(wave_shr1(sgr));   // below chunk q: what chunk q+1 shows from above; 0 under the last
+        const double sa = wscan_apply(dS[q] + kS * (rho * dS[q] + sig),
+                                      [&](int k) { return sStep[(size_t)(WSCAN_STEPS + k) * blockDim.x]; });
+        const double d_in = wave_shr1(sa);
         Din[q] = d_in;
-        Uin[q] = mm * (rho * dS[q] + sg[q] + rho * dD * d_in);
+        Uin[q] = mm * (rho * dS[q] + sig + rho * dD * d_in);
       }
       // level fluxes (:288-293), g-point weight; column q of the group goes to staging buffer q
 #pragma unroll
@@ -2034,7 +2099,7 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
 bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s) {
   const int lmax = (p.nz + 63) / 64;
   if (p.ng > IRB_WAVES || lmax > 4 || p.n_ir <= 0 || ncol <= 0) return false;
-  const size_t lds = sizeof(double) * ((size_t)(IRB_TILE + 4 * IRB_WAVES) * ((size_t)p.nz + 1) + 12 * 64 * IRB_WAVES);
+  const size_t lds = sizeof(double) * ((size_t)(IRB_TILE + 4 * IRB_WAVES) * ((size_t)p.nz + 1) + 2 * WSCAN_STEPS * 64 * IRB_WAVES);
   if (lds > 160 * 1024) return false;
   static bool attr = false;
   if (!attr) {

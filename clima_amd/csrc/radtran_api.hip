@@ -1229,6 +1229,19 @@ void clima_test_device_exp(const int *n, const double *x, double *y, char *err) 
   CATCH(err)
 }
 
+void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, double *out, char *err) {
+  clear_err(err);
+  TRY
+  const size_t n = (size_t)*nwaves * 64;
+  DevBuf<double> da, db, dout;
+  da.alloc(n); db.alloc(n); dout.alloc(4 * n);
+  HIPCHK(hipMemcpy(da.p, a, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db.p, b, sizeof(double) * n, hipMemcpyHostToDevice));
+  launch_test_wscan(da.p, db.p, dout.p, *nwaves, nullptr);
+  HIPCHK(hipMemcpy(out, dout.p, sizeof(double) * 4 * n, hipMemcpyDeviceToHost));
+  CATCH(err)
+}
+
 // ---- reference-named getters / setters (clima/fortran/Radtran.f90) -------------------
 
 static double bolometric(Radtran *r) {  // Radtran_bolometric_flux, clima_radtran.f90:353-364

@@ -165,6 +165,9 @@ void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double 
 
 /* test hook: y[i] = the kernels' device exp(x[i]) (used where the reference calls exp) */
 void clima_test_device_exp(const int *n, const double *x, double *y, char *err);
+/* test hook: the DPP wave scans of the kernels on nwaves*64 values (out: 4 arrays of that length:
+ * affine inclusive scan, the same through build+apply, shift up by one lane, lane reversal) */
+void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, double *out, char *err);
 
 /* OpticalPropertiesResult (clima_radtran_types.f90:242-247), for parity checks:
  * tau,w0 (nz,ngauss,nw) and g,tau_band (nz,nw), column-major, TOA-first. */

@@ -92,6 +92,33 @@ def test_device_exp(hip_lib):
     assert np.all(np.abs(y[~normal & (ref > 0) & np.isfinite(ref)] - ref[~normal & (ref > 0) & np.isfinite(ref)]) <= 1e-300)
 
 
+def test_dpp_wave_scans(hip_lib):
+    # the DPP-based affine wave scan used by the batched IR kernel, against a serial recurrence
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    nw = 5
+    a = rng.normal(size=nw * 64)
+    b = rng.uniform(0.2, 1.1, size=nw * 64) * rng.choice([1.0, -1.0], size=nw * 64)
+    out = np.empty(4 * nw * 64)
+    err = C.create_string_buffer(1025)
+    dp = C.POINTER(C.c_double)
+    hip_lib.clima_test_wave_scan(C.byref(C.c_int(nw)), a.ctypes.data_as(dp), b.ctypes.data_as(dp), out.ctypes.data_as(dp), err)
+    assert err.value == b""
+    out = out.reshape(4, nw, 64)
+    A, B = a.reshape(nw, 64), b.reshape(nw, 64)
+    want = np.empty_like(A)
+    for w in range(nw):
+        x = 0.0
+        for i in range(64):
+            x = A[w, i] + B[w, i] * x
+            want[w, i] = x
+    np.testing.assert_allclose(out[0], want, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(out[1], want, rtol=1e-12, atol=1e-13)
+    shifted = np.concatenate([np.zeros((nw, 1)), A[:, :-1]], axis=1)
+    np.testing.assert_array_equal(out[2], shifted)
+    np.testing.assert_array_equal(out[3], A[:, ::-1])
+
+
 def test_config1_modern_earth_50_layers(O, small_tables):
     # BASELINE.json configs[0]: ModernEarth, 50 layers, 1 zenith angle, albedo 0.3
     from clima_amd import synthetic as S
