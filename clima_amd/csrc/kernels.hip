@@ -221,6 +221,8 @@ __device__ __forceinline__ double lerp1(const double *f, int i, double q) {
 }
 
 constexpr int OP_THREADS = 256;
+// s_getreg operand: HW_REG_HW_ID (id 4), field WAVE_ID (offset 0, 4 bits) -- the wave's slot on its SIMD
+constexpr int HWREG_HW_ID_WAVE_ID = (3 << 11) | (0 << 6) | 4;
 
 // Device-scope accesses for data handed from one block to another INSIDE a launch (k_fused):
 // stores write through and loads bypass the per-XCD L2, so no cache-wide writeback /
@@ -407,74 +409,86 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   const double dzj = c.dz[j];
 
   STAMP(p.stamps, 0);
-  // ---- Rayleigh (:686-693)
-  double tausg = 0.0;
-#pragma unroll 4
-  for (int i = 0; i < p.nray; i++) tausg = tausg + p.ray[i].data[l] * c.cols[p.ray[i].sp1 * nz + j];
-  // ---- continuum absorption: CIA, photolysis/absorption, H2O continuum (:665-677, :696-723).
-  // Entries are processed eight at a time with every load of the batch issued before the
-  // first use, so the dependent index -> table round trips overlap instead of queueing.
-  double taua = 0.0;
-  constexpr int AB = 8;
-  for (int e0 = 0; e0 < p.nabs; e0 += AB) {
-    int ixx[AB];
-    double qq[AB], ww[AB];
-#pragma unroll
-    for (int u = 0; u < AB; u++) {
-      const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
-      ixx[u] = c.ix[x.slot * nz + j];
-      qq[u] = c.q[x.slot * nz + j];
-      ww[u] = c.absw[min(e0 + u, p.nabs - 1) * nz + j];
-    }
-    double v0[AB], v1[AB];
-#pragma unroll
-    for (int u = 0; u < AB; u++) {
-      const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
-      const double *base = x.data + (x.nT ? (size_t)l * x.nT + ixx[u] : (size_t)l);
-      v0[u] = base[0];
-      v1[u] = base[x.nT ? 1 : 0];
-    }
-#pragma unroll
-    for (int u = 0; u < AB; u++) {
-      if (e0 + u < p.nabs) {
-        const AbsEntry &x = p.abs[e0 + u];
-        double sgm = v0[u];
-        if (x.nT) sgm = ten2power((1.0 - qq[u]) * v0[u] + qq[u] * v1[u]);  // lerp1 + ten2power (:910-912)
-        taua = taua + sgm * ww[u];
+  // Everything of the layer that is not a k-distribution (Rayleigh, continuum, custom and particle
+  // opacity) is needed only by the totals at the end, so it can run before or after the mixing
+  // loop.  The two waves that share a SIMD take opposite orders (hardware wave-slot parity): one
+  // is in this load-latency-bound part while the other is in the VALU-bound sort/rebin, instead of
+  // both stalling on memory at the same time.
+  double tausg, taua, tauc, tausc, taup, tausp, gt;
+  auto layer_terms = [&]() {
+    // ---- Rayleigh (:686-693)
+    tausg = 0.0;
+  #pragma unroll 4
+    for (int i = 0; i < p.nray; i++) tausg = tausg + p.ray[i].data[l] * c.cols[p.ray[i].sp1 * nz + j];
+    // ---- continuum absorption: CIA, photolysis/absorption, H2O continuum (:665-677, :696-723).
+    // Entries are processed eight at a time with every load of the batch issued before the
+    // first use, so the dependent index -> table round trips overlap instead of queueing.
+    taua = 0.0;
+    constexpr int AB = 8;
+    for (int e0 = 0; e0 < p.nabs; e0 += AB) {
+      int ixx[AB];
+      double qq[AB], ww[AB];
+  #pragma unroll
+      for (int u = 0; u < AB; u++) {
+        const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
+        ixx[u] = c.ix[x.slot * nz + j];
+        qq[u] = c.q[x.slot * nz + j];
+        ww[u] = c.absw[min(e0 + u, p.nabs - 1) * nz + j];
+      }
+      double v0[AB], v1[AB];
+  #pragma unroll
+      for (int u = 0; u < AB; u++) {
+        const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
+        const double *base = x.data + (x.nT ? (size_t)l * x.nT + ixx[u] : (size_t)l);
+        v0[u] = base[0];
+        v1[u] = base[x.nT ? 1 : 0];
+      }
+  #pragma unroll
+      for (int u = 0; u < AB; u++) {
+        if (e0 + u < p.nabs) {
+          const AbsEntry &x = p.abs[e0 + u];
+          double sgm = v0[u];
+          if (x.nT) sgm = ten2power((1.0 - qq[u]) * v0[u] + qq[u] * v1[u]);  // lerp1 + ten2power (:910-912)
+          taua = taua + sgm * ww[u];
+        }
       }
     }
-  }
-  // ---- custom opacity (:540-572, :726-730); tiny everywhere when unset (:558-562)
-  double tauc = TINY, tausc = TINY * TINY, g0c = TINY;
-  if constexpr (CUSTOM) {
-    const int ix = c.ix[p.cust.slot * nz + j];
-    const double q = c.q[p.cust.slot * nz + j];
-    const size_t o = (size_t)l * p.cust.nP;
-    tauc = lerp1(p.cust.dtau + o, ix, q) * dzj;
-    const double w0c = lerp1(p.cust.w0 + o, ix, q);
-    g0c = lerp1(p.cust.g0 + o, ix, q);
-    tausc = w0c * tauc;
-  }
-  // ---- particles (:680-683, :733-757)
-  double tausp = 0.0, taup = 0.0;
-  double tausp_1[MAX_PART], gtp[MAX_PART];
-  for (int i = 0; i < p.npart; i++) {
-    const PartDev &pt = p.part[i];
-    const int ix = c.ix[pt.slot * nz + j];
-    const double q = c.q[pt.slot * nz + j];
-    const double w0p = lerp1(pt.w0 + (size_t)l * pt.nrad, ix, q);
-    const double qext = lerp1(pt.qext + (size_t)l * pt.nrad, ix, q);
-    gtp[i] = lerp1(pt.gt + (size_t)l * pt.nrad, ix, q);
-    const double rr = c.radii[pt.p_ind * nz + j];
-    const double taup_1 = qext * PI * (rr * rr) * c.pdens[pt.p_ind * nz + j] * dzj;
-    taup = taup + taup_1;
-    tausp_1[i] = w0p * taup_1;
-    tausp = tausp + tausp_1[i];
-  }
-  double gt = 0.0;
-  for (int i = 0; i < p.npart; i++) gt = gt + gtp[i] * tausp_1[i] / fmax(TAU_MIN, (tausp + tausg + tausc));
-  gt = gt + g0c * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
-  gt = fmin(gt, MAX_GT);
+    // ---- custom opacity (:540-572, :726-730); tiny everywhere when unset (:558-562)
+    tauc = TINY; tausc = TINY * TINY;
+    double g0c = TINY;
+    if constexpr (CUSTOM) {
+      const int ix = c.ix[p.cust.slot * nz + j];
+      const double q = c.q[p.cust.slot * nz + j];
+      const size_t o = (size_t)l * p.cust.nP;
+      tauc = lerp1(p.cust.dtau + o, ix, q) * dzj;
+      const double w0c = lerp1(p.cust.w0 + o, ix, q);
+      g0c = lerp1(p.cust.g0 + o, ix, q);
+      tausc = w0c * tauc;
+    }
+    // ---- particles (:680-683, :733-757)
+    tausp = 0.0; taup = 0.0;
+    double tausp_1[MAX_PART], gtp[MAX_PART];
+    for (int i = 0; i < p.npart; i++) {
+      const PartDev &pt = p.part[i];
+      const int ix = c.ix[pt.slot * nz + j];
+      const double q = c.q[pt.slot * nz + j];
+      const double w0p = lerp1(pt.w0 + (size_t)l * pt.nrad, ix, q);
+      const double qext = lerp1(pt.qext + (size_t)l * pt.nrad, ix, q);
+      gtp[i] = lerp1(pt.gt + (size_t)l * pt.nrad, ix, q);
+      const double rr = c.radii[pt.p_ind * nz + j];
+      const double taup_1 = qext * PI * (rr * rr) * c.pdens[pt.p_ind * nz + j] * dzj;
+      taup = taup + taup_1;
+      tausp_1[i] = w0p * taup_1;
+      tausp = tausp + tausp_1[i];
+    }
+    gt = 0.0;
+    for (int i = 0; i < p.npart; i++) gt = gt + gtp[i] * tausp_1[i] / fmax(TAU_MIN, (tausp + tausg + tausc));
+    gt = gt + g0c * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
+    gt = fmin(gt, MAX_GT);
+
+  };
+  const bool terms_first = (__builtin_amdgcn_s_getreg(HWREG_HW_ID_WAVE_ID) & 1) == 0;
+  if (terms_first) layer_terms();
 
   STAMP(p.stamps, 1);
   // ---- k-distributions (:649-662) and random-overlap mixing (k_rorr :816-854)
@@ -528,6 +542,7 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
       STAMP(p.stamps, 4 + 3 * s);
     }
   }
+  if (!terms_first) layer_terms();
   STAMP(p.stamps, 20);
 #ifdef CLIMA_STAMPS
   if (p.stamps && (tid & 63) == 0) {
