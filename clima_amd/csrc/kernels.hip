@@ -2151,7 +2151,7 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
     // the opr stores above went out at device scope (write-through); wait until they are
     // acknowledged, then let every wave of the block arrive before the flag goes up
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): this wave's write-through stores have been acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&fp.done[blockIdx.x], fp.call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;

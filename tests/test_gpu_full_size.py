@@ -113,3 +113,31 @@ def test_separate_launch_form_at_full_size(nominal):
     b = r.TOA_fluxes(*col.args())
     r.fused = True
     assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(a[1])
+
+
+def test_fused_handoff_is_fresh_under_alternating_columns(nominal):
+    """The fused grid hands the opacities from producer to consumer blocks inside one launch
+    (device-scope stores / loads, no cache-wide fences).  A stale read would return the PREVIOUS
+    call's opacities, so alternate between different columns: every call must reproduce the
+    separate-launch results of its own column (opacities bit for bit, fluxes to rounding)."""
+    from clima_amd import synthetic as S
+    tb, r, col = nominal
+    cols = [col] + S.perturbed_columns(2, 200, seed=11)
+
+    def run(c):
+        r.upload_column(*c.args())
+        r.radiate_resident()
+        r.synchronize()
+        return np.array(r.f_total), np.array(r.wrk_sol.fup_n), np.array(r.wrk_ir.fup_n)
+
+    r.fused = False
+    ref = [run(c) + tuple(a.copy() for a in r.opr()) for c in cols]
+    r.fused = True
+    for i in range(240):
+        k = i % len(cols)
+        got = run(cols[k])
+        for a, b in zip(got, ref[k][:3]):
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-10 * np.max(np.abs(b)))
+        if i % 40 < len(cols):
+            for a, b in zip(r.opr(), ref[k][3:]):
+                np.testing.assert_array_equal(a, b)
