@@ -112,6 +112,23 @@ program radtran_driver
     call rad%radiate_ir_batch(Tsb, Tb, bup, bdn, bft, err); call check()
     write(u,'(es26.17e3)') bft
   end block
+
+  ! custom optical properties (clima_radtran.f90:494-512): a grey absorber-scatterer, then unset
+  block
+    real(dp) :: wv(3), Pc(3), dtau(3,3), w0c(3,3), g0c(3,3), ISR2, OLR2
+    wv = [2.0e2_dp, 1.0e3_dp, 1.0e5_dp]
+    Pc = [1.0e6_dp, 1.0e4_dp, 1.0e2_dp]
+    dtau = 3.0e-8_dp; w0c = 0.5_dp; g0c = 0.3_dp
+    call rad%set_custom_optical_properties(wv, Pc, dtau, w0c, g0c, err); call check()
+    if (np > 0) then
+      call rad%TOA_fluxes(T_surface, T, P, densities, dz, pdensities, radii, ISR=ISR2, OLR=OLR2, err=err)
+    else
+      call rad%TOA_fluxes(T_surface, T, P, densities, dz, ISR=ISR2, OLR=OLR2, err=err)
+    endif
+    call check()
+    write(u,'(2es26.17e3)') ISR2, OLR2
+    call rad%unset_custom_optical_properties()
+  end block
   close(u)
 
   ! error convention: allocated err <=> failure, reference message text

@@ -36,6 +36,7 @@ def test_fortran_driver_matches_python_and_oracle(O, tmp_path):
     ir_toa = vals[p:p + nw_ir]; p += nw_ir
     sol_toa = vals[p:p + nw_sol]; p += nw_sol
     batch_ft = vals[p:p + 3 * (nz + 1)].reshape(3, nz + 1).T; p += 3 * (nz + 1)
+    isr_c, olr_c = vals[p], vals[p + 1]; p += 2
     assert p == len(vals)
     # printed quantity of tests/test_radtran.f90:73
     assert abs(float(out.stdout.split()[0]) - sol_fdn_n[nz] * 1e-3) < 1e-9 * abs(sol_fdn_n[nz] * 1e-3)
@@ -55,6 +56,13 @@ def test_fortran_driver_matches_python_and_oracle(O, tmp_path):
     _, _, ft = r.radiate_ir_batch(Ts, Tb)
     assert np.array_equal(batch_ft, ft)                         # Fortran and Python reach the same kernel
     np.testing.assert_allclose(ft[:, 0], np.array(r.f_total), rtol=1e-11, atol=1e-11 * np.max(np.abs(ft)))
+
+    # type-bound set_custom_optical_properties
+    wv, Pc = np.array([2.0e2, 1.0e3, 1.0e5]), np.array([1.0e6, 1.0e4, 1.0e2])
+    r.set_custom_optical_properties(wv, Pc, np.full((3, 3), 3.0e-8), np.full((3, 3), 0.5), np.full((3, 3), 0.3))
+    assert (isr_c, olr_c) == r.TOA_fluxes(*col.args())
+    r.unset_custom_optical_properties()
+    assert (isr_c, olr_c) != (isr, olr)
 
     o = O.OracleRadtran(tb, nz, nzen, albedo)
     isr_o, olr_o = o.TOA_fluxes(*col.args())
