@@ -124,6 +124,9 @@ struct Radtran {
   DevBuf<double> d_zen_u, d_zen_w, d_zen_iu, d_partial, d_albedo, d_emis, d_photons, d_am_f1, d_am_f2, d_am_dw;
   // column + prep
   int nslots = 0;
+  // names for opacities2yaml (the loaders know them; optional: radtran_set_names / radtran_set_opacity_labels)
+  std::vector<std::string> species_names, particle_names, particle_data;
+  std::string k_method_name = "RandomOverlapResortRebin", continuum_model = "MT_CKD";
   std::vector<SlotDev> slots;
   // custom optical properties (types.f90:432-548): tables [nw][nP] on the device, axis log10(P cgs) ascending
   bool cust_on = false;
@@ -779,6 +782,103 @@ void radtran_set_custom_optical_properties(void *ptr, const int *dim_wv, const d
   r->d_cust_axis.upload(lp); r->d_cust_dtau.upload(tab[0]); r->d_cust_w0.upload(tab[1]); r->d_cust_g0.upload(tab[2]);
   r->cust_on = true;
   CATCH(err)
+}
+
+static std::vector<std::string> split_lines(const char *s) {
+  std::vector<std::string> out;
+  if (!s) return out;
+  std::string cur;
+  for (const char *c = s; *c; c++) {
+    if (*c == '\n') { out.push_back(cur); cur.clear(); } else cur.push_back(*c);
+  }
+  if (!cur.empty()) out.push_back(cur);
+  return out;
+}
+
+// Names the loaders know and opacities2yaml prints: species / particles in index order, one per
+// line (OpticalProperties%species_names, %particle_names, clima_radtran_types.f90:100-101)
+void radtran_set_names(void *ptr, const char *species_names, const char *particle_names, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  auto sp = split_lines(species_names), pa = split_lines(particle_names);
+  if (r->state >= 1 && ((int)sp.size() != r->nsp || (int)pa.size() != r->np)) {
+    set_err(err, "radtran_set_names: the number of names does not match the number of species / particles");
+    return;
+  }
+  r->species_names = sp; r->particle_names = pa;
+}
+
+// k-method name (Ksettings%k_method_name), water-continuum model (WaterContinuum%model) and the
+// data-set name of every particle cross section in the order they were added (ParticleXsection%dat_name)
+void radtran_set_opacity_labels(void *ptr, const char *k_method, const char *water_continuum_model,
+                                const char *particle_data, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (k_method && k_method[0]) r->k_method_name = k_method;
+  if (water_continuum_model && water_continuum_model[0]) r->continuum_model = water_continuum_model;
+  r->particle_data = split_lines(particle_data);
+}
+
+// OpticalProperties_opacities2yaml, clima_radtran_types.f90:328-430 (line by line)
+static std::string opacities2yaml(Radtran *r) {
+  auto sp = [&](int i) { return (i >= 0 && i < (int)r->species_names.size()) ? r->species_names[i] : ("species" + std::to_string(i + 1)); };
+  auto join = [](const std::vector<std::string> &v) {
+    std::string o;
+    for (size_t i = 0; i < v.size(); i++) { o += v[i]; if (i + 1 != v.size()) o += ", "; }
+    return o;
+  };
+  std::string out = "  k-method: " + r->k_method_name;
+  out += "\n  opacities:";
+  if (!r->k.empty()) {
+    std::vector<std::string> v;
+    for (auto *k : r->k) v.push_back(sp(k->sp));
+    out += "\n    k-distributions: [" + join(v) + "]";
+  }
+  if (!r->cia.empty()) {
+    std::vector<std::string> v;
+    for (auto *x : r->cia) v.push_back(sp(x->sp1) + "-" + sp(x->sp2));
+    out += "\n    CIA: [" + join(v) + "]";
+  }
+  if (!r->ray.empty()) {
+    std::vector<std::string> v;
+    for (auto *x : r->ray) v.push_back(sp(x->sp1));
+    out += "\n    rayleigh: [" + join(v) + "]";
+  }
+  if (!r->pxs.empty()) {
+    std::vector<std::string> v;
+    for (auto *x : r->pxs) v.push_back(sp(x->sp1));
+    out += "\n    photolysis-xs: [" + join(v) + "]";
+  }
+  if (r->has_cont) out += "\n    water-continuum: " + r->continuum_model;
+  if (!r->part.empty()) {
+    std::vector<std::string> v;
+    for (size_t i = 0; i < r->part.size(); i++) {
+      const int pi = r->part[i]->p_ind;
+      const std::string name = (pi >= 0 && pi < (int)r->particle_names.size()) ? r->particle_names[pi] : ("particle" + std::to_string(pi + 1));
+      const std::string dat = i < r->particle_data.size() ? r->particle_data[i] : std::string("unknown");
+      v.push_back("{name: " + name + ", data: " + dat + "}");
+    }
+    out += "\n    particle-xs: [" + join(v) + "]";
+  }
+  return out;
+}
+
+// clima/fortran/Radtran.f90:41-75: _1 allocates the C string and returns its length, _2 copies it
+// into the caller's buffer (out_len + 1 chars) and frees it
+void radtran_opacities2yaml_wrapper_1(void *ptr, int *out_len, void **out_cp) {
+  Radtran *r = as_rad(ptr);
+  const std::string s = r ? opacities2yaml(r) : std::string();
+  char *buf = (char *)std::malloc(s.size() + 1);
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  *out_len = (int)s.size();
+  *out_cp = buf;
+}
+void radtran_opacities2yaml_wrapper_2(void *ptr, void **out_cp, const int *out_len, char *out_c) {
+  (void)ptr;
+  if (!out_cp || !*out_cp) return;
+  std::memcpy(out_c, *out_cp, (size_t)*out_len + 1);
+  std::free(*out_cp);
+  *out_cp = nullptr;
 }
 
 void radtran_fused_set(void *ptr, const int *enable) {

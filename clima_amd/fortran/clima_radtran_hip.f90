@@ -75,6 +75,8 @@ module clima_radtran_hip
     procedure :: equilibrium_temperature => Radtran_equilibrium_temperature
     procedure :: apply_radiation_enhancement => Radtran_apply_radiation_enhancement
     procedure :: radiate_ir_batch => Radtran_radiate_ir_batch
+    procedure :: opacities2yaml => Radtran_opacities2yaml
+    procedure :: set_names => Radtran_set_names
     procedure :: set_custom_optical_properties => Radtran_set_custom_optical_properties
     procedure :: unset_custom_optical_properties => Radtran_unset_custom_optical_properties
     procedure :: destroy => Radtran_destroy
@@ -155,6 +157,22 @@ module clima_radtran_hip
       integer(c_int), intent(in) :: ncol, dim1_T, dim2_T
       real(c_double), intent(in) :: T_surface(*), T(*)
       real(c_double), intent(out) :: fup_n(*), fdn_n(*), f_total(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_opacities2yaml_wrapper_1(ptr, out_len, out_cp) bind(c, name="radtran_opacities2yaml_wrapper_1")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(out) :: out_len
+      type(c_ptr), intent(out) :: out_cp
+    end subroutine
+    subroutine c_radtran_opacities2yaml_wrapper_2(ptr, out_cp, out_len, out_c) bind(c, name="radtran_opacities2yaml_wrapper_2")
+      import; type(c_ptr), value :: ptr
+      type(c_ptr), intent(inout) :: out_cp
+      integer(c_int), intent(in) :: out_len
+      character(c_char), intent(out) :: out_c(*)
+    end subroutine
+    subroutine c_radtran_set_names(ptr, species_names, particle_names, err) bind(c, name="radtran_set_names")
+      import; type(c_ptr), value :: ptr
+      character(c_char), intent(in) :: species_names(*), particle_names(*)
       character(c_char), intent(out) :: err(*)
     end subroutine
     subroutine c_radtran_set_custom_optical_properties(ptr, dim_wv, wv, dim_P, P, dim1_t, dim2_t, dtau_dz, &
@@ -627,6 +645,55 @@ contains
     call take_err(err_c, err)
     if (allocated(err)) return
     fup_n = a; fdn_n = b; f_total = c
+  end subroutine
+
+  !> clima_radtran.f90 `opacities2yaml` (-> clima_radtran_types.f90:328-430)
+  function Radtran_opacities2yaml(self) result(out)
+    class(Radtran), intent(inout) :: self
+    character(:), allocatable :: out
+    integer(c_int) :: n
+    type(c_ptr) :: cp
+    character(c_char), allocatable :: buf(:)
+    integer :: i
+    call c_radtran_opacities2yaml_wrapper_1(self%handle, n, cp)
+    allocate(buf(n+1))
+    call c_radtran_opacities2yaml_wrapper_2(self%handle, cp, n, buf)
+    allocate(character(n) :: out)
+    do i = 1, n
+      out(i:i) = buf(i)
+    enddo
+  end function
+
+  !> species / particle names (index order) that opacities2yaml prints
+  subroutine Radtran_set_names(self, species_names, particle_names, err)
+    class(Radtran), intent(inout) :: self
+    character(*), intent(in) :: species_names(:), particle_names(:)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    character(:), allocatable :: s1, s2
+    integer :: i
+    s1 = ''
+    do i = 1, size(species_names)
+      s1 = s1//trim(species_names(i))
+      if (i /= size(species_names)) s1 = s1//new_line('a')
+    enddo
+    s2 = ''
+    do i = 1, size(particle_names)
+      s2 = s2//trim(particle_names(i))
+      if (i /= size(particle_names)) s2 = s2//new_line('a')
+    enddo
+    call c_radtran_set_names(self%handle, to_c(s1), to_c(s2), err_c)
+    call take_err(err_c, err)
+  contains
+    function to_c(s) result(c)
+      character(*), intent(in) :: s
+      character(c_char) :: c(len(s)+1)
+      integer :: k
+      do k = 1, len(s)
+        c(k) = s(k:k)
+      enddo
+      c(len(s)+1) = c_null_char
+    end function
   end subroutine
 
   !> clima_radtran.f90:494-506

@@ -130,6 +130,8 @@ program radtran_driver
     call rad%unset_custom_optical_properties()
   end block
   close(u)
+  write(output_unit,'(a)') 'opacities2yaml:'
+  write(output_unit,'(a)') rad%opacities2yaml()
 
   ! error convention: allocated err <=> failure, reference message text
   if (np > 0) then

@@ -35,6 +35,10 @@ SIGNATURES = {
     "radtran_apply_radiation_enhancement": [_vp, _dp],
     "radtran_set_custom_optical_properties": [_vp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, _err],
     "radtran_unset_custom_optical_properties": [_vp],
+    "radtran_opacities2yaml_wrapper_1": [_vp, _ip, _vpp],
+    "radtran_opacities2yaml_wrapper_2": [_vp, _vpp, _ip, _err],
+    "radtran_set_names": [_vp, _err, _err, _err],
+    "radtran_set_opacity_labels": [_vp, _err, _err, _err, _err],
     "radtran_fused_set": [_vp, _ip],
     "radtran_fused_get": [_vp, _ip],
     "radtran_radiate_ir_batch": [_vp, _ip, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _err],

@@ -145,6 +145,15 @@ class Radtran:
         self._check()
         self.nw = t.nw
         self.ngauss = t.ng
+        # names for opacities2yaml (clima_radtran_types.f90:328-430)
+        L.radtran_set_names(self._ptr, "\n".join(self.species_names).encode(), "\n".join(self.particle_names).encode(),
+                            self._err)
+        self._check()
+        cont = t.continuum.get("model", "MT_CKD") if t.continuum is not None else ""
+        L.radtran_set_opacity_labels(self._ptr, str(getattr(t, "k_method_name", "RandomOverlapResortRebin")).encode(),
+                                     str(cont).encode(),
+                                     "\n".join(str(p.get("dat_name", "unknown")) for p in t.particles).encode(), self._err)
+        self._check()
 
     @classmethod
     def from_files(cls, settings_f, star_f, num_zenith_angles, surface_albedo, nz, datadir):
@@ -210,6 +219,14 @@ class Radtran:
 
     def apply_radiation_enhancement(self, rad_enhancement):
         self._L.radtran_apply_radiation_enhancement(self._ptr, _f(rad_enhancement))
+
+    def opacities2yaml(self):
+        """Radtran%opacities2yaml (clima/cython/Radtran.pyx:68-81): YAML text naming every opacity."""
+        n, cp = C.c_int(), C.c_void_p()
+        self._L.radtran_opacities2yaml_wrapper_1(self._ptr, C.byref(n), C.byref(cp))
+        buf = C.create_string_buffer(n.value + 1)
+        self._L.radtran_opacities2yaml_wrapper_2(self._ptr, C.byref(cp), C.byref(n), buf)
+        return buf.value.decode()
 
     def set_custom_optical_properties(self, wv, P, dtau_dz, w0, g0):
         """Radtran%set_custom_optical_properties (src/radtran/clima_radtran.f90:494-506): `wv` nm,

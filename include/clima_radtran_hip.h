@@ -141,6 +141,17 @@ void radtran_finish_reduced(void *ptr, char *err);
 void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
                               const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
                               double *f_total, char *err);
+/* clima/fortran/Radtran.f90:41-75 (same names and argument lists): the YAML text of
+ * OpticalProperties_opacities2yaml (src/radtran/clima_radtran_types.f90:328-430).  _1 allocates
+ * the string and returns its length, _2 copies it into out_c (out_len + 1 chars) and frees it.
+ * The names it prints come from radtran_set_names / radtran_set_opacity_labels (what the loaders
+ * know: species and particle names one per line in index order; k-method, water-continuum model,
+ * one data-set name per added particle cross section). */
+void radtran_opacities2yaml_wrapper_1(void *ptr, int *out_len, void **out_cp);
+void radtran_opacities2yaml_wrapper_2(void *ptr, void **out_cp, const int *out_len, char *out_c);
+void radtran_set_names(void *ptr, const char *species_names, const char *particle_names, char *err);
+void radtran_set_opacity_labels(void *ptr, const char *k_method, const char *water_continuum_model,
+                                const char *particle_data, char *err);
 /* Launch form of a compute_opacity call: 1 (default) = opacity and two-stream work in one grid
  * (k_fused: two-stream blocks start as soon as the opacity blocks of their bin are done),
  * 0 = one launch per kernel.  Same results to rounding; CLIMA_HIP_FUSED=0 sets the default off. */

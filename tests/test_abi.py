@@ -67,3 +67,61 @@ def test_no_cpu_fallback_in_product():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".f90")):
                 src = open(os.path.join(base, f), errors="ignore").read()
                 assert "import oracle" not in src and "from oracle" not in src and "liborc" not in src, f
+
+
+def test_opacities2yaml_text(hip_lib):
+    """radtran_opacities2yaml_wrapper_{1,2} (clima/fortran/Radtran.f90:41-75) print what
+    OpticalProperties_opacities2yaml prints (clima_radtran_types.f90:328-430); the tables and names
+    are host-side state, so this needs no device."""
+    import numpy as np
+    L = hip_lib
+    err = C.create_string_buffer(1025)
+    h = C.c_void_p()
+    L.allocate_radtran(C.byref(h))
+    dp = C.POINTER(C.c_double)
+
+    def i(v):
+        return C.byref(C.c_int(v))
+
+    def d(a):
+        return a.ctypes.data_as(dp)
+
+    nw, ng, nP, nT = 4, 8, 3, 3
+    wavl = np.linspace(100.0, 500.0, nw + 1)
+    L.radtran_create_begin(h, i(5), i(3), i(1), i(nw), d(wavl), err)
+    assert err.value == b""
+    w = np.full(ng, 1.0 / ng)
+    lp, tt, kk = np.linspace(-3, 0, nP), np.linspace(100.0, 300.0, nT), np.zeros(nw * nT * nP * ng)
+    for sp in (1, 3):
+        L.radtran_add_ktable(h, i(sp), i(ng), d(w), i(nP), d(lp), i(nT), d(tt), d(kk), err)
+        assert err.value == b""
+    xs1 = np.zeros(nw * nT)
+    L.radtran_add_xsection(h, i(0), i(1), i(2), i(2), i(nT), d(tt), d(xs1), err)   # CIA N2-N2
+    L.radtran_add_xsection(h, i(0), i(1), i(3), i(2), i(nT), d(tt), d(xs1), err)   # CIA CO2-N2
+    xs0 = np.zeros(nw)
+    L.radtran_add_xsection(h, i(1), i(0), i(3), i(0), i(0), d(tt), d(xs0), err)    # Rayleigh CO2
+    L.radtran_add_xsection(h, i(3), i(0), i(1), i(0), i(0), d(tt), d(xs0), err)    # photolysis H2O
+    L.radtran_set_water_continuum(h, i(1), i(nT), d(tt), d(xs1), d(xs1), err)
+    rad = np.array([1e-6, 1e-4])
+    pt = np.zeros(nw * 2)
+    L.radtran_add_particle(h, i(1), i(2), d(rad), d(pt), d(pt), d(pt), err)
+    assert err.value == b""
+    L.radtran_set_names(h, b"H2O\nN2\nCO2", b"HCaer1", err)
+    assert err.value == b""
+    L.radtran_set_opacity_labels(h, b"RandomOverlapResortRebin", b"MT_CKD", b"khare1984", err)
+    n, cp = C.c_int(), C.c_void_p()
+    L.radtran_opacities2yaml_wrapper_1(h, C.byref(n), C.byref(cp))
+    buf = C.create_string_buffer(n.value + 1)
+    L.radtran_opacities2yaml_wrapper_2(h, C.byref(cp), C.byref(n), buf)
+    assert buf.value.decode() == (
+        "  k-method: RandomOverlapResortRebin\n"
+        "  opacities:\n"
+        "    k-distributions: [H2O, CO2]\n"
+        "    CIA: [N2-N2, CO2-N2]\n"
+        "    rayleigh: [CO2]\n"
+        "    photolysis-xs: [H2O]\n"
+        "    water-continuum: MT_CKD\n"
+        "    particle-xs: [{name: HCaer1, data: khare1984}]")
+    L.radtran_set_names(h, b"H2O\nN2", b"HCaer1", err)
+    assert b"does not match" in err.value
+    L.deallocate_radtran(h)

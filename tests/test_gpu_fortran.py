@@ -26,6 +26,7 @@ def test_fortran_driver_matches_python_and_oracle(O, tmp_path):
     out = subprocess.run([exe, case, res], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'expected error: "T" has the wrong input dimension.' in out.stdout
+    assert "opacities2yaml:\n  k-method: RandomOverlapResortRebin\n  opacities:\n    k-distributions: [" in out.stdout
     vals = np.array(open(res).read().split(), dtype=float)
     nw_ir, nw_sol = len(tb.ir_wavl) - 1, len(tb.sol_wavl) - 1
     isr, olr = vals[0], vals[1]
