@@ -93,7 +93,13 @@ def main():
     # partial fluxes and the library stream waits for the reduced ones -- no host round trip
     # inside a step.  CLIMA_BENCH_HOST_SYNC=1 selects the plain host-synchronised form.
     host_sync = os.environ.get("CLIMA_BENCH_HOST_SYNC") == "1"
-    lib_stream = torch.cuda.ExternalStream(rad.stream()) if dist_on and not host_sync else None
+    lib_stream = None
+    if dist_on and not host_sync:
+        try:
+            lib_stream = torch.cuda.ExternalStream(rad.stream())
+        except Exception as e:  # same torch build on every rank: all of them take the same branch
+            print("bench: torch.cuda.ExternalStream unavailable (%s); host-synchronised steps" % e, file=sys.stderr)
+            host_sync = True
 
     def step():
         rad.radiate_resident()
