@@ -324,8 +324,13 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
 #undef CE
   STAMP(g_stamp_buf, 30 + g_stamp_step);
   double S = 0.0, c0 = 0.0;
-  int k = 1;                          // next output edge to pass: E[k]
-  double bk = E[1], bn = E[2];        // E[k], E[k+1] (prefetched)
+  // Next output edge to pass is E[k]: bk = E[k], `en` points at E[k+1] in the LDS edge table and
+  // bn = *en is prefetched; `slot` is where I(E_k) goes.  Running pointers instead of k keep the
+  // crossing block (which some lane of the wave needs at nearly every element) short.
+  double bk = E[1], bn = E[2];
+  const double *en = s_E + 2;
+  double *slot = &sI[0][tid];
+  double *const slot_end = &sI[0][tid] + 8 * OP_THREADS;
   // weights_to_bins (clima_eqns.f90:43-54) on wxy(inds): the LDS lookups run one batch of
   // RB elements ahead of their use, so a batch pays one wait instead of one per element
   constexpr int RB = 8;
@@ -348,24 +353,26 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
       const double w = wv[u];
       const double c1 = c0 + w;
       if (c1 > bk) {                    // this element reaches past E[k]
-        sI[k - 1][tid] = __builtin_fma(v, bk - c0, S);
-        k++;
+        *slot = __builtin_fma(v, bk - c0, S);
+        slot += OP_THREADS;
         bk = bn;
+        en++;
         if constexpr (MULTI) {
           while (c1 > bk) {             // one element spanning a whole output bin: only possible
-            sI[k - 1][tid] = __builtin_fma(v, bk - c0, S);  // when max(wxy) > min(wbin)
-            k++;
-            bk = s_E[k];
+            *slot = __builtin_fma(v, bk - c0, S);  // when max(wxy) > min(wbin)
+            slot += OP_THREADS;
+            bk = *en;
+            en++;
           }
         }
       }
-      bn = s_E[k + 1];  // refreshed unconditionally (unchanged if nothing was crossed): the
-                        // lookup is then consumed one element later instead of at the branch join
+      bn = *en;  // refreshed unconditionally (unchanged if nothing was crossed): the lookup is
+                 // then consumed one element later instead of at the branch join
       S = __builtin_fma(v, w, S);
       c0 = c1;
     }
   }
-  for (; k <= 8; k++) sI[k - 1][tid] = S;  // edges at or beyond the total weight (rounding)
+  for (; slot < slot_end; slot += OP_THREADS) *slot = S;  // edges at or beyond the total weight (rounding)
   double Ik[8];
 #pragma unroll
   for (int q = 0; q < 8; q++) Ik[q] = sI[q][tid];
