@@ -290,6 +290,9 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
     key[a] = lo_;                             \
     key[b] = hi_;                             \
   }
+// exchanges that operands ascending in both x and y never need (sort_network_64.inc)
+#define CE_X(a, b) \
+  if (!xys) CE(a, b)
   const bool ys = __all(ysorted), xys = ys && __all(xsorted);
   if (!ys) {
 #define CE_FULL_HEAD
@@ -321,6 +324,7 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
 #define CE_L32_REST
 #include "sort_network_64.inc"
 #undef CE_L32_REST
+#undef CE_X
 #undef CE
   STAMP(g_stamp_buf, 30 + g_stamp_step);
   double S = 0.0, c0 = 0.0;

@@ -85,6 +85,53 @@ def check_tableau(n, run, st, trials=5000):
         assert v == sorted(v)
 
 
+def monotone01(run):
+    """All 0/1 matrices (run x run, row-major = key order i*run+j) that are non-decreasing along
+    rows and columns: C(2*run, run) of them (12 870 for run = 8)."""
+    import numpy as np
+    out = []
+
+    def rec(i, prev, cs):
+        if i == run:
+            out.append([1 if j >= cs[r] else 0 for r in range(run) for j in range(run)])
+            return
+        for c in range(0, prev + 1):
+            rec(i + 1, c, cs + [c])
+    rec(0, run, [])
+    return np.array(out, dtype=np.uint8)
+
+
+def sorts_all(net, M):
+    import numpy as np
+    V = M.copy()
+    for a, b in net:
+        lo = np.minimum(V[:, a], V[:, b])
+        hi = np.maximum(V[:, a], V[:, b])
+        V[:, a] = lo
+        V[:, b] = hi
+    return bool(np.all(V[:, :-1] <= V[:, 1:]))
+
+
+def tableau_prune(n, run, st):
+    """Which exchanges of the merge levels (first stages already left out) can be dropped when the
+    keys are x_i + y_j with x and y both ascending, i.e. a matrix sorted along rows and columns.
+    A comparison network sorts every such real matrix iff it sorts every such 0/1 matrix
+    (thresholding commutes with compare-exchange) and there are only C(2 run, run) of those, so
+    every step of the greedy pruning (last exchange to first) is checked exhaustively.
+    Returns {(p, k, position in stage): True if droppable}."""
+    assert n == run * run
+    M = monotone01(run)
+    items = [(p, k, i, ce) for p, k, ces in st if p >= run and k != p for i, ce in enumerate(ces)]
+    assert sorts_all([it[3] for it in items], M)
+    alive = [True] * len(items)
+    for idx in range(len(items) - 1, -1, -1):
+        alive[idx] = False
+        if not sorts_all([it[3] for it, a in zip(items, alive) if a], M):
+            alive[idx] = True
+    assert sorts_all([it[3] for it, a in zip(items, alive) if a], M)
+    return {(p, k, i): (not a) for (p, k, i, ce), a in zip(items, alive)}, len(M)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     run = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -98,6 +145,8 @@ def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "clima_amd", "csrc",
                        "sort_network_%d.inc" % n)
     nfirst = sum(len(c) for p, k, c in st if p >= run and k == p)
+    drop, ncases = tableau_prune(n, run, st) if n == run * run else ({}, 0)
+    ndrop = sum(drop.values())
     with open(out, "w") as f:
         f.write("// Generated by tools/gen_sort_network.py %d %d -- do not edit.\n" % (n, run))
         f.write("// Batcher odd-even merge sort (Knuth's merge exchange), %d keys: %d compare-exchanges.\n" % (n, len(full)))
@@ -106,6 +155,9 @@ def main():
         f.write("//   CE_L<p>_FIRST     : first stage of merge level p (%d exchanges in all); redundant when the keys\n" % nfirst)
         f.write("//                       are x_i + y_j with BOTH x and y ascending (elementwise-ordered runs)\n")
         f.write("//   CE_L<p>_REST      : the remaining stages of level p (%d exchanges in all)\n" % (len(merge) - nfirst))
+        f.write("//   CE_X              : %d of those exchanges are never needed when BOTH x and y are ascending (keys sorted\n" % ndrop)
+        f.write("//                       along rows and columns): pruned greedily, every step checked on all %d such 0/1\n" % ncases)
+        f.write("//                       matrices (zero-one principle for that input class); the includer defines CE_X\n")
         f.write("#ifdef CE_FULL_HEAD\n")
         for p, k, ces in st:
             if p < run:
@@ -122,11 +174,11 @@ def main():
             f.write("#endif\n#ifdef CE_L%d_REST\n" % p)
             for pp, k, ces in st:
                 if pp == p and k != p:
-                    for a, b in ces:
-                        f.write("CE(%d,%d)\n" % (a, b))
+                    for i, (a, b) in enumerate(ces):
+                        f.write("%s(%d,%d)\n" % ("CE_X" if drop.get((pp, k, i)) else "CE", a, b))
             f.write("#endif\n")
             p *= 2
-    print("n=%d full=%d merge_tail=%d (first stages %d) -> %s" % (n, len(full), len(merge), nfirst, os.path.abspath(out)))
+    print("n=%d full=%d merge_tail=%d (first stages %d, droppable for ordered operands %d) -> %s" % (n, len(full), len(merge), nfirst, ndrop, os.path.abspath(out)))
 
 
 if __name__ == "__main__":
