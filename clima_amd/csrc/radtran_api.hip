@@ -162,6 +162,9 @@ struct Radtran {
   int op_lo = 0, op_n = 0, ir_lo = 0, ir_n = 0, sol_lo = 0, sol_n = 0;
   // stream + profiling
   hipStream_t stream = nullptr;
+  // column batches (radtran_toa_fluxes_batch): the column / level-flux buffers a call works on
+  double *col_override = nullptr, *flux_override = nullptr, *ftot_override = nullptr;
+  DevBuf<double> d_cols_arena, d_flux_arena;
   bool batch_shared = true;        // radiate_ir_batch: temperature-independent work shared by the columns (CLIMA_HIP_BATCH_SHARED=0: one full solve per column)
   bool fused = true;               // opacity + two-stream in one grid (k_fused); CLIMA_HIP_FUSED=0 or radtran_fused_set turns it off
   DevBuf<int> d_done;              // per opacity block: call id of its last completed run
@@ -360,7 +363,7 @@ void resolve_events(Radtran *r) {
 ColumnDev column_dev(Radtran *r) {
   ColumnDev c;
   const int nz = r->nz;
-  double *base = r->d_col.p;
+  double *base = r->col_override ? r->col_override : r->d_col.p;
   c.T_surface = base;
   c.T = base + 1;
   c.P = c.T + nz;
@@ -511,8 +514,8 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   ip.ir_fup_a = r->wrk_ir.fup_a.p; ip.ir_fdn_a = r->wrk_ir.fdn_a.p;
   ip.sol_fup_a = r->wrk_sol.fup_a.p; ip.sol_fdn_a = r->wrk_sol.fdn_a.p;
   ip.ir_freq = r->ir.d_freq.p; ip.sol_freq = r->sol.d_freq.p;
-  ip.flux_n = r->d_flux_n.p;
-  ip.f_total = r->shard_world == 1 ? r->d_f_total.p : nullptr;
+  ip.flux_n = r->flux_override ? r->flux_override : r->d_flux_n.p;
+  ip.f_total = r->shard_world == 1 ? (r->ftot_override ? r->ftot_override : r->d_f_total.p) : nullptr;
   ip.nchunk = integrate_chunks(std::max(r->ir_n, r->sol_n));
   ip.partial = r->d_partial.p;
   { KernelTimer t(r, 3); launch_integrate(ip, r->stream); t.stop(); }
@@ -1108,6 +1111,83 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
       fdn_n[(size_t)c * nl + i] = out[((size_t)c * 3 + 1) * nl + i];
       f_total[(size_t)c * nl + i] = out[((size_t)c * 3 + 2) * nl + i];
     }
+  CATCH(err)
+}
+
+// Config 4 of BASELINE.json (many independent columns): every column is one full
+// Radtran%TOA_fluxes (clima_radtran.f90:320-342), but the batch is moved to HBM in one copy, the
+// calls are enqueued back to back with no host round trip between them, and the level fluxes
+// come back in one copy.  Arrays carry the column as their LAST (slowest) dimension:
+// T, P, dz (nz, ncol); densities (nz, nsp, ncol); pdensities, radii (nz, np, ncol).
+// Outputs: ISR, OLR (ncol); fluxes (nz+1, 5, ncol) = ir up, ir down, solar up, solar down, f_total,
+// or NULL.  The handle's own wrk / f_total hold the last column afterwards.
+void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surface, const double *T, const double *P,
+                              const double *densities, const double *dz, const int *has_particles,
+                              const double *pdensities, const double *radii, double *ISR, double *OLR,
+                              double *fluxes, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  if (*ncol < 1) { set_err(err, "\"T\" has the wrong input dimension."); return; }
+  if (r->shard_world != 1) { set_err(err, "toa_fluxes_batch is not available on a bin-sharded handle"); return; }
+  const int hp = has_particles ? *has_particles : 0;
+  if (r->np > 0 && !hp) { set_err(err, "\"pdensities\" and \"radii\" are required arguments."); return; }
+  TRY
+  const int nz = r->nz, nl = nz + 1, n = *ncol;
+  const size_t cc = r->col_count;
+  std::vector<double> h((size_t)n * cc);
+  for (int c = 0; c < n; c++) {  // the device layout of one column (do_upload)
+    double *d = h.data() + (size_t)c * cc;
+    d[0] = T_surface[c];
+    std::memcpy(d + 1, T + (size_t)c * nz, sizeof(double) * nz);
+    std::memcpy(d + 1 + nz, P + (size_t)c * nz, sizeof(double) * nz);
+    std::memcpy(d + 1 + 2 * nz, dz + (size_t)c * nz, sizeof(double) * nz);
+    std::memcpy(d + 1 + 3 * nz, densities + (size_t)c * nz * r->nsp, sizeof(double) * (size_t)nz * r->nsp);
+    double *dp = d + 1 + 3 * nz + (size_t)nz * r->nsp;
+    if (r->np > 0) {
+      std::memcpy(dp, pdensities + (size_t)c * nz * r->np, sizeof(double) * (size_t)nz * r->np);
+      std::memcpy(dp + (size_t)nz * r->np, radii + (size_t)c * nz * r->np, sizeof(double) * (size_t)nz * r->np);
+    }
+  }
+  if (r->d_cols_arena.n < h.size()) r->d_cols_arena.alloc(h.size());
+  if (r->d_flux_arena.n < (size_t)n * 5 * nl) r->d_flux_arena.alloc((size_t)n * 5 * nl);
+  HIPCHK(hipMemcpyAsync(r->d_cols_arena.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, r->stream));
+  r->column_has_particles = r->np > 0;
+  const int first_call = r->call_id + 1;
+  for (int c = 0; c < n; c++) {
+    r->col_override = r->d_cols_arena.p + (size_t)c * cc;
+    r->flux_override = r->d_flux_arena.p + (size_t)c * 5 * nl;
+    r->ftot_override = r->flux_override + 4 * nl;
+    try {
+      enqueue_radiate(r, true, true);
+    } catch (...) {
+      r->col_override = r->flux_override = r->ftot_override = nullptr;
+      throw;
+    }
+  }
+  r->col_override = r->flux_override = r->ftot_override = nullptr;
+  std::vector<double> out((size_t)n * 5 * nl);
+  HIPCHK(hipMemcpyAsync(out.data(), r->d_flux_arena.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, sizeof(int), hipMemcpyDeviceToHost, r->stream));
+  // the handle's own level fluxes = the last column's
+  HIPCHK(hipMemcpyAsync(r->d_flux_n.p, r->d_flux_arena.p + (size_t)(n - 1) * 5 * nl, sizeof(double) * 4 * nl, hipMemcpyDeviceToDevice, r->stream));
+  HIPCHK(hipMemcpyAsync(r->d_f_total.p, r->d_flux_arena.p + (size_t)(n - 1) * 5 * nl + 4 * nl, sizeof(double) * nl, hipMemcpyDeviceToDevice, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  resolve_events(r);
+  r->small_valid = false;
+  r->column_loaded = false;   // d_col does not hold the last column: a resident call needs an upload first
+  if (*r->h_errflag >= first_call) {
+    r->checked_id = r->call_id;
+    set_err(err, "Opacity computation failed in one or more wavelength bins.");  // clima_radtran_types.f90:773-776
+    return;
+  }
+  r->checked_id = r->call_id;
+  for (int c = 0; c < n; c++) {
+    const double *f = out.data() + (size_t)c * 5 * nl;
+    ISR[c] = f[3 * nl + nz] - f[2 * nl + nz];        // clima_radtran.f90:339-340
+    OLR[c] = -(f[1 * nl + nz] - f[0 * nl + nz]);
+    if (fluxes) std::memcpy(fluxes + (size_t)c * 5 * nl, f, sizeof(double) * 5 * nl);
+  }
   CATCH(err)
 }
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "radtran_set_opacity_labels": [_vp, _err, _err, _err, _err],
     "radtran_fused_set": [_vp, _ip],
     "radtran_fused_get": [_vp, _ip],
+    "radtran_toa_fluxes_batch": [_vp, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _err],
     "radtran_radiate_ir_batch": [_vp, _ip, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _err],
     "radtran_upload_column": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],
     "radtran_radiate_resident": [_vp, _ip, _ip, _err],

@@ -246,6 +246,39 @@ class Radtran:
         """src/radtran/clima_radtran.f90:508-512"""
         self._L.radtran_unset_custom_optical_properties(self._ptr)
 
+    def TOA_fluxes_batch(self, columns, return_fluxes=False):
+        """Many independent columns (BASELINE config 4): `columns` is a sequence of column dicts /
+        `synthetic.Column`s (T_surface, T, P, densities, dz[, pdensities, radii]).  Returns
+        (ISR, OLR) arrays, plus the level fluxes (nz+1, 5, ncol) = ir up, ir down, solar up,
+        solar down, f_total when `return_fluxes`."""
+        n = len(columns)
+        nz = self.nz
+        Ts = np.array([float(c["T_surface"]) for c in columns])
+        T = np.stack([np.asarray(c["T"], dtype=np.float64) for c in columns])           # (ncol, nz)
+        P = np.stack([np.asarray(c["P"], dtype=np.float64) for c in columns])
+        dz = np.stack([np.asarray(c["dz"], dtype=np.float64) for c in columns])
+        dens = np.stack([np.asarray(c["densities"], dtype=np.float64).T for c in columns])  # (ncol, nsp, nz)
+        if T.shape != (n, nz) or dens.shape != (n, self.ng, nz):
+            raise ClimaException('"densities" has the wrong input dimension.')
+        hp = self.np > 0
+        if hp:
+            if any(c.get("radii") is None for c in columns):
+                raise ClimaException('"pdensities" and "radii" are required arguments.')
+            pd = np.stack([np.asarray(c["pdensities"], dtype=np.float64).T for c in columns])
+            ra = np.stack([np.asarray(c["radii"], dtype=np.float64).T for c in columns])
+        else:
+            pd = ra = np.zeros(1)
+        isr, olr = np.empty(n), np.empty(n)
+        fl = np.empty((n, 5, nz + 1)) if return_fluxes else None
+        self._L.radtran_toa_fluxes_batch(self._ptr, _i(n), _d(Ts), _d(np.ascontiguousarray(T)), _d(np.ascontiguousarray(P)),
+                                         _d(np.ascontiguousarray(dens)), _d(np.ascontiguousarray(dz)), _i(1 if hp else 0),
+                                         _d(np.ascontiguousarray(pd)), _d(np.ascontiguousarray(ra)), _d(isr), _d(olr),
+                                         _d(fl) if return_fluxes else None, self._err)
+        self._check()
+        if return_fluxes:
+            return isr, olr, np.transpose(fl, (2, 1, 0))
+        return isr, olr
+
     def radiate_ir_batch(self, T_surface, T):
         """ncol IR-only calls with the resident opacities in one go: column c is
         `radiate(T_surface[c], T[:, c], ..., compute_solar=False, compute_opacity=False)`

@@ -132,6 +132,15 @@ void radtran_bin_shard_get(void *ptr, int *op_lo, int *op_n, int *ir_lo, int *ir
                            int *sol_n);
 /* after an external all-reduce of the flux buffer: recompute f_total on the device */
 void radtran_finish_reduced(void *ptr, char *err);
+/* Column batch (BASELINE.json config 4): ncol independent Radtran%TOA_fluxes calls
+ * (src/radtran/clima_radtran.f90:320-342), moved to HBM in one copy and enqueued back to back.
+ * Inputs as radtran_toa_fluxes_wrapper with the column as the last dimension: T, P, dz (nz, ncol),
+ * densities (nz, nsp, ncol), pdensities / radii (nz, np, ncol), T_surface (ncol).  ISR, OLR (ncol);
+ * fluxes (nz+1, 5, ncol) = ir up, ir down, solar up, solar down, f_total, or NULL. */
+void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surface, const double *T, const double *P,
+                              const double *densities, const double *dz, const int *has_particles,
+                              const double *pdensities, const double *radii, double *ISR, double *OLR,
+                              double *fluxes, char *err);
 /* Batched shared-opacity IR calls: what the RCE Jacobian does one call at a time
  * (src/adiabat/clima_adiabat_solve.f90:798-812 -> clima_radtran.f90:221-318 with
  * compute_solar = compute_opacity = .false.).  T is (nz, ncol) column-major, T_surface (ncol);

@@ -424,6 +424,30 @@ def test_constructed_from_a_data_directory(O, tmp_path):
     _compare(r, o, S.modern_earth_column(40))
 
 
+def test_column_batch_equals_one_call_per_column(O, small_tables):
+    # BASELINE config 4 mechanics: radtran_toa_fluxes_batch enqueues the same kernels per column
+    # without host round trips, so every column equals its own TOA_fluxes call bit for bit
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    nz = 50
+    cols = S.perturbed_columns(9, nz, seed=3)
+    r = Radtran(small_tables, nz, 2, 0.3)
+    isr, olr, fl = r.TOA_fluxes_batch(cols, return_fluxes=True)
+    assert fl.shape == (nz + 1, 5, len(cols))
+    last_ft = np.array(r.f_total)
+    np.testing.assert_array_equal(last_ft, fl[:, 4, -1])        # the handle holds the last column
+    for c, col in enumerate(cols):
+        one = r.TOA_fluxes(*col.args())
+        assert one == (isr[c], olr[c])
+        np.testing.assert_array_equal(np.array(r.wrk_ir.fup_n), fl[:, 0, c])
+        np.testing.assert_array_equal(np.array(r.wrk_sol.fdn_n), fl[:, 3, c])
+        np.testing.assert_array_equal(np.array(r.f_total), fl[:, 4, c])
+    o = O.OracleRadtran(small_tables, nz, 2, 0.3)
+    for c in (0, 4, 8):
+        isr_o, olr_o = o.TOA_fluxes(*cols[c].args())
+        assert abs(olr[c] - olr_o) <= RTOL_TOA * abs(olr_o) and abs(isr[c] - isr_o) <= RTOL_TOA * abs(isr_o)
+
+
 def test_radiation_enhancement_and_bolometric(O, small_tables):
     from clima_amd import synthetic as S
     col = S.modern_earth_column(50)
