@@ -75,6 +75,7 @@ module clima_radtran_hip
     procedure :: equilibrium_temperature => Radtran_equilibrium_temperature
     procedure :: apply_radiation_enhancement => Radtran_apply_radiation_enhancement
     procedure :: radiate_ir_batch => Radtran_radiate_ir_batch
+    procedure :: TOA_fluxes_batch => Radtran_TOA_fluxes_batch
     procedure :: opacities2yaml => Radtran_opacities2yaml
     procedure :: set_names => Radtran_set_names
     procedure :: set_custom_optical_properties => Radtran_set_custom_optical_properties
@@ -150,6 +151,14 @@ module clima_radtran_hip
     subroutine c_radtran_apply_radiation_enhancement(ptr, rad_enhancement) bind(c, name="radtran_apply_radiation_enhancement")
       import; type(c_ptr), value :: ptr
       real(c_double), intent(in) :: rad_enhancement
+    end subroutine
+    subroutine c_radtran_toa_fluxes_batch(ptr, ncol, T_surface, T, P, densities, dz, has_particles, pdensities, radii, &
+                                          ISR, OLR, fluxes, err) bind(c, name="radtran_toa_fluxes_batch")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: ncol, has_particles
+      real(c_double), intent(in) :: T_surface(*), T(*), P(*), densities(*), dz(*), pdensities(*), radii(*)
+      real(c_double), intent(out) :: ISR(*), OLR(*), fluxes(*)
+      character(c_char), intent(out) :: err(*)
     end subroutine
     subroutine c_radtran_radiate_ir_batch(ptr, ncol, T_surface, dim1_T, dim2_T, T, fup_n, fdn_n, f_total, err) &
                                           bind(c, name="radtran_radiate_ir_batch")
@@ -617,6 +626,31 @@ contains
     class(Radtran), target, intent(inout) :: self
     real(dp), intent(in) :: rad_enhancement
     call c_radtran_apply_radiation_enhancement(self%handle, rad_enhancement)
+    call pull_results(self, .true.)
+  end subroutine
+
+  !> Many independent columns (the column is the last dimension of every array): each one a full
+  !> `TOA_fluxes` (clima_radtran.f90:320-342), enqueued back to back on the device.
+  !> `fluxes(nz+1, 5, ncol)` = ir up, ir down, solar up, solar down, f_total.
+  subroutine Radtran_TOA_fluxes_batch(self, T_surface, T, P, densities, dz, pdensities, radii, ISR, OLR, fluxes, err)
+    class(Radtran), intent(inout) :: self
+    real(dp), intent(in) :: T_surface(:), T(:,:), P(:,:), densities(:,:,:), dz(:,:)
+    real(dp), intent(in) :: pdensities(:,:,:), radii(:,:,:)
+    real(dp), intent(out) :: ISR(:), OLR(:), fluxes(:,:,:)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    integer :: ncol
+    ncol = size(T_surface)
+    if (size(T,1) /= self%nz .or. size(T,2) /= ncol .or. any(shape(densities) /= [self%nz, self%ng, ncol]) .or. &
+        any(shape(fluxes) /= [self%nz+1, 5, ncol]) .or. size(ISR) /= ncol .or. size(OLR) /= ncol) then
+      err = '"T" has the wrong input dimension.'
+      return
+    endif
+    call push_fields(self)
+    call c_radtran_toa_fluxes_batch(self%handle, ncol, T_surface, T, P, densities, dz, merge(1, 0, self%np > 0), &
+                                    pdensities, radii, ISR, OLR, fluxes, err_c)
+    call take_err(err_c, err)
+    if (allocated(err)) return
     call pull_results(self, .true.)
   end subroutine
 

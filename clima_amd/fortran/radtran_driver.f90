@@ -113,6 +113,24 @@ program radtran_driver
     write(u,'(es26.17e3)') bft
   end block
 
+  ! two independent columns in one batch (the second 1 K warmer): column 1 must reproduce the call above
+  block
+    real(dp) :: Tsb(2), Tb(nz,2), Pb(nz,2), db(nz,nsp,2), dzb(nz,2), ISRb(2), OLRb(2), fl(nz+1,5,2)
+    real(dp), allocatable :: pdb(:,:,:), rab(:,:,:)
+    allocate(pdb(nz,max(np,1),2), rab(nz,max(np,1),2))
+    Tsb = [T_surface, T_surface + 1.0_dp]
+    Tb(:,1) = T; Tb(:,2) = T + 1.0_dp
+    Pb(:,1) = P; Pb(:,2) = P
+    db(:,:,1) = densities; db(:,:,2) = densities
+    dzb(:,1) = dz; dzb(:,2) = dz
+    pdb = 1.0_dp; rab = 1.0e-5_dp
+    if (np > 0) then
+      pdb(:,:,1) = pdensities; pdb(:,:,2) = pdensities; rab(:,:,1) = radii; rab(:,:,2) = radii
+    endif
+    call rad%TOA_fluxes_batch(Tsb, Tb, Pb, db, dzb, pdb(:,1:np,:), rab(:,1:np,:), ISRb, OLRb, fl, err); call check()
+    write(u,'(4es26.17e3)') ISRb, OLRb
+  end block
+
   ! custom optical properties (clima_radtran.f90:494-512): a grey absorber-scatterer, then unset
   block
     real(dp) :: wv(3), Pc(3), dtau(3,3), w0c(3,3), g0c(3,3), ISR2, OLR2

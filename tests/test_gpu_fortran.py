@@ -37,6 +37,7 @@ def test_fortran_driver_matches_python_and_oracle(O, tmp_path):
     ir_toa = vals[p:p + nw_ir]; p += nw_ir
     sol_toa = vals[p:p + nw_sol]; p += nw_sol
     batch_ft = vals[p:p + 3 * (nz + 1)].reshape(3, nz + 1).T; p += 3 * (nz + 1)
+    isr_b, olr_b = vals[p:p + 2], vals[p + 2:p + 4]; p += 4
     isr_c, olr_c = vals[p], vals[p + 1]; p += 2
     assert p == len(vals)
     # printed quantity of tests/test_radtran.f90:73
@@ -57,6 +58,10 @@ def test_fortran_driver_matches_python_and_oracle(O, tmp_path):
     _, _, ft = r.radiate_ir_batch(Ts, Tb)
     assert np.array_equal(batch_ft, ft)                         # Fortran and Python reach the same kernel
     np.testing.assert_allclose(ft[:, 0], np.array(r.f_total), rtol=1e-11, atol=1e-11 * np.max(np.abs(ft)))
+
+    # type-bound TOA_fluxes_batch: column 1 is the driver's own column, column 2 is 1 K warmer
+    full = r.TOA_fluxes(*col.args())
+    assert (isr_b[0], olr_b[0]) == full and olr_b[1] > olr_b[0]
 
     # type-bound set_custom_optical_properties
     wv, Pc = np.array([2.0e2, 1.0e3, 1.0e5]), np.array([1.0e6, 1.0e4, 1.0e2])
