@@ -47,6 +47,8 @@ __device__ __forceinline__ double dmax(double a, double b) {
   return r;
 }
 // 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (no scaling: |x| is O(1) where this is used)
+// v_rcp_f64 alone is good to ~2^-24; one Newton step leaves up to 2e-15, two give the correctly
+// rounded reciprocal on 4e5 test values (tests/devtools/gpu_rcp_accuracy.py)
 __device__ __forceinline__ double rcp_nr(double x) {
   double r = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, r, 1.0);
@@ -2383,6 +2385,21 @@ __global__ void k_scale(double *a, size_t n, double f) {
 __global__ void k_test_exp(const double *x, double *y, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = fast_exp(x[i]);
+}
+__global__ void k_test_rcp(const double *x, double *y, int n) {
+  // y[0..n): raw v_rcp_f64; [n..2n): one Newton step; [2n..3n): two (rcp_nr)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = x[i];
+  double r = __builtin_amdgcn_rcp(v);
+  y[i] = r;
+  double e = __builtin_fma(-v, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  y[n + i] = r;
+  y[2 * n + i] = rcp_nr(v);
+}
+void launch_test_rcp(const double *x, double *y, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_test_rcp, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
 }
 void launch_test_exp(const double *x, double *y, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_test_exp, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);

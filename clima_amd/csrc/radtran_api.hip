@@ -1409,6 +1409,17 @@ void clima_test_device_exp(const int *n, const double *x, double *y, char *err) 
   CATCH(err)
 }
 
+void clima_test_device_rcp(const int *n, const double *x, double *y, char *err) {
+  clear_err(err);
+  TRY
+  DevBuf<double> dx, dy;
+  dx.alloc(*n); dy.alloc((size_t)3 * *n);
+  HIPCHK(hipMemcpy(dx.p, x, sizeof(double) * *n, hipMemcpyHostToDevice));
+  launch_test_rcp(dx.p, dy.p, *n, nullptr);
+  HIPCHK(hipMemcpy(y, dy.p, sizeof(double) * 3 * *n, hipMemcpyDeviceToHost));
+  CATCH(err)
+}
+
 void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, double *out, char *err) {
   clear_err(err);
   TRY

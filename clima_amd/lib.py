@@ -58,6 +58,7 @@ SIGNATURES = {
     "radtran_algorithmic_bytes": [_vp, _dp, _dp, _dp, _dp, _err],
     "radtran_opr_get": [_vp, _dp, _dp, _dp, _dp, _err],
     "clima_test_device_exp": [_ip, _dp, _dp, _err],
+    "clima_test_device_rcp": [_ip, _dp, _dp, _err],
     "clima_test_wave_scan": [_ip, _dp, _dp, _dp, _err],
     "radtran_set_bolometric_flux_wrapper": [_vp, _dp],
     "radtran_bolometric_flux_wrapper": [_vp, _dp],
