@@ -141,3 +141,37 @@ def test_fused_handoff_is_fresh_under_alternating_columns(nominal):
         if i % 40 < len(cols):
             for a, b in zip(r.opr(), ref[k][3:]):
                 np.testing.assert_array_equal(a, b)
+
+
+def _full_size_against_oracle(O, tb, nz, nzen, albedo, col, **scalars):
+    from clima_amd.radtran import Radtran
+    r = Radtran(tb, nz, nzen, albedo)
+    o = O.OracleRadtran(tb, nz, nzen, albedo)
+    for k, v in scalars.items():
+        setattr(r, k, v)
+    if scalars:
+        o.set_scalars(**scalars)
+    isr, olr = r.TOA_fluxes(*col.args())
+    isr_o, olr_o = o.TOA_fluxes(*col.args())
+    assert abs(olr - olr_o) <= 1e-9 * abs(olr_o) and abs(isr - isr_o) <= 1e-9 * abs(isr_o)
+    for wg, wo in ((r.wrk_ir, o.wrk_ir), (r.wrk_sol, o.wrk_sol)):
+        for a, b in ((wg.fup_n, wo.fup_n), (wg.fdn_n, wo.fdn_n)):
+            assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b))
+    assert np.max(np.abs(np.array(r.f_total) - np.array(o.f_total))) <= 1e-9 * np.max(np.abs(o.f_total))
+    for a, b in zip(r.opr(), o.opr()):
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)) <= 1e-11
+
+
+def test_config3_early_mars_full_size(O):
+    """BASELINE.json configs[2]: CO2-dominated, CIA-heavy, 200 layers, 1000 bins, 4 zenith angles,
+    photon scale factor of Mars (templates/AdiabatClimate/Mars/settings.yaml)."""
+    from clima_amd import synthetic as S
+    _full_size_against_oracle(O, S.early_mars_tables(), 200, 4, 0.2, S.early_mars_column(200),
+                              photon_scale_factor=0.4286)
+
+
+def test_config5_500_layers_full_size(O):
+    """BASELINE.json configs[4] column shape at the full bin count (the bins are what an 8-GPU run
+    shards; test_bin_sharded_partials_add_up covers the sharding itself)."""
+    from clima_amd import synthetic as S
+    _full_size_against_oracle(O, S.modern_earth_tables(), 500, 8, 0.15, S.modern_earth_column(500))
