@@ -146,6 +146,8 @@ struct Radtran {
   size_t col_count = 0;
   bool column_has_particles = false;
   bool column_loaded = false;
+  hipEvent_t ev_upload = nullptr;   // marks the end of the last column copy out of the pinned staging buffer
+  bool upload_pending = false;
   int call_id = 0, checked_id = 0;  // opacity passes enqueued / already checked for device errors
   std::vector<double> last_T, last_P, last_radii;  // host copy for byte accounting
   // opr
@@ -189,6 +191,7 @@ struct Radtran {
     if (h_col) (void)hipHostFree(h_col);
     if (h_small) (void)hipHostFree(h_small);
     if (h_errflag) (void)hipHostFree(h_errflag);
+    if (ev_upload) (void)hipEventDestroy(ev_upload);
     if (stream) (void)hipStreamDestroy(stream);
     magic = 0;
   }
@@ -552,6 +555,8 @@ void do_upload(Radtran *r, double T_surface, const double *T, const double *P, c
                const double *dz, const double *pdens, const double *radii) {
   const int nz = r->nz;
   double *h = r->h_col;
+  // the pinned staging buffer is reused: wait (lazily, here) for the previous upload's copy
+  if (r->upload_pending) { HIPCHK(hipEventSynchronize(r->ev_upload)); r->upload_pending = false; }
   h[0] = T_surface;
   std::memcpy(h + 1, T, sizeof(double) * nz);
   std::memcpy(h + 1 + nz, P, sizeof(double) * nz);
@@ -564,8 +569,8 @@ void do_upload(Radtran *r, double T_surface, const double *T, const double *P, c
   }
   r->column_has_particles = (pdens && radii);
   HIPCHK(hipMemcpyAsync(r->d_col.p, h, sizeof(double) * r->col_count, hipMemcpyHostToDevice, r->stream));
-  // the staging buffer is reused by the next upload: wait for the copy (tiny)
-  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(hipEventRecord(r->ev_upload, r->stream));
+  r->upload_pending = true;
   r->last_T.assign(T, T + nz);
   r->last_P.assign(P, P + nz);
   if (r->np > 0 && radii) r->last_radii.assign(radii, radii + (size_t)nz * r->np); else r->last_radii.clear();
@@ -927,6 +932,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   HIPCHK(hipGetDeviceCount(&dev_count));
   if (dev_count < 1) throw HipFail{"no HIP device available: the Radtran hot path has no CPU fallback"};
   HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&r->ev_upload, hipEventDisableTiming));
   if (const char *f = getenv("CLIMA_HIP_FUSED")) r->fused = atoi(f) != 0;
   if (const char *f = getenv("CLIMA_HIP_BATCH_SHARED")) r->batch_shared = atoi(f) != 0;
 
