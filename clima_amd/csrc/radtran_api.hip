@@ -47,6 +47,11 @@ template <class T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
+  bool owned = true;
+  void view(T *ptr, size_t count) {  // a window into another buffer (not freed here)
+    release();
+    p = ptr; n = count; owned = false;
+  }
   void alloc(size_t count) {
     release();
     n = count;
@@ -60,9 +65,10 @@ struct DevBuf {
     if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s));
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    owned = true;
   }
   ~DevBuf() { release(); }
 };
@@ -154,7 +160,8 @@ struct Radtran {
   DevBuf<double> d_tau, d_w0, d_g, d_tau_band;
   bool opr_valid = false;
   // results
-  DevBuf<double> d_flux_n, d_f_total;
+  DevBuf<double> d_small;     // flux_n[4*(nz+1)] | f_total[nz+1] | err flag slot: one D2H copy per call
+  DevBuf<double> d_flux_n, d_f_total;   // views into d_small
   double *h_small = nullptr;  // pinned: flux_n[4*(nz+1)] | f_total[nz+1] | err flag (as double slot)
   int *h_errflag = nullptr;
   std::vector<double> f_total;
@@ -190,7 +197,6 @@ struct Radtran {
     for (auto &e : pool) (void)hipEventDestroy(e);
     if (h_col) (void)hipHostFree(h_col);
     if (h_small) (void)hipHostFree(h_small);
-    if (h_errflag) (void)hipHostFree(h_errflag);
     if (ev_upload) (void)hipEventDestroy(ev_upload);
     if (stream) (void)hipStreamDestroy(stream);
     magic = 0;
@@ -528,9 +534,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
 void fetch_small(Radtran *r) {
   if (r->small_valid) return;
   const int nl = r->nz + 1;
-  HIPCHK(hipMemcpyAsync(r->h_small, r->d_flux_n.p, sizeof(double) * 4 * nl, hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipMemcpyAsync(r->h_small + 4 * nl, r->d_f_total.p, sizeof(double) * nl, hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, sizeof(int), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipMemcpyAsync(r->h_small, r->d_small.p, sizeof(double) * (5 * nl + 1), hipMemcpyDeviceToHost, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   resolve_events(r);
   r->small_valid = true;
@@ -1005,7 +1009,6 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   r->d_log10P.alloc(nz); r->d_cols.alloc((size_t)nz * r->nsp); r->d_foreign.alloc(nz);
   r->d_absw.alloc((size_t)std::max<size_t>(1, r->abs_entries.size()) * nz);
   r->d_src.alloc(nz); r->d_ix.alloc((size_t)(r->nslots + 1) * nz); r->d_q.alloc((size_t)(r->nslots + 1) * nz);
-  r->d_err.alloc(1); r->d_err.zero();
   r->d_done.alloc(((size_t)nw * nz + 255) / 256 + 1); r->d_done.zero();
 #ifdef CLIMA_STAMPS
   r->d_stamps.alloc(64 + 2 * 8192); r->d_stamps.zero();
@@ -1021,13 +1024,14 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   };
   mk(r->wrk_ir, 0, r->ir.nw);
   mk(r->wrk_sol, 1, r->sol.nw);
-  r->d_flux_n.alloc((size_t)4 * (nz + 1)); r->d_flux_n.zero();
+  r->d_small.alloc((size_t)5 * (nz + 1) + 1); r->d_small.zero();
+  r->d_flux_n.view(r->d_small.p, (size_t)4 * (nz + 1));
+  r->d_err.view(reinterpret_cast<int *>(r->d_small.p + (size_t)5 * (nz + 1)), 1);
   r->d_partial.alloc((size_t)4 * integrate_chunks(std::max(r->ir.nw, r->sol.nw)) * (nz + 1)); r->d_partial.zero();
-  r->d_f_total.alloc(nz + 1); r->d_f_total.zero();
-  HIPCHK(hipHostMalloc((void **)&r->h_small, sizeof(double) * 5 * (nz + 1)));
-  std::memset(r->h_small, 0, sizeof(double) * 5 * (nz + 1));
-  HIPCHK(hipHostMalloc((void **)&r->h_errflag, sizeof(int)));
-  *r->h_errflag = 0;
+  r->d_f_total.view(r->d_small.p + (size_t)4 * (nz + 1), nz + 1);
+  HIPCHK(hipHostMalloc((void **)&r->h_small, sizeof(double) * (5 * (nz + 1) + 1)));
+  std::memset(r->h_small, 0, sizeof(double) * (5 * (nz + 1) + 1));
+  r->h_errflag = reinterpret_cast<int *>(r->h_small + 5 * (nz + 1));
   r->f_total.assign(nz + 1, 0.0);
   HIPCHK(hipDeviceSynchronize());
   r->fields_dirty = true;
