@@ -122,17 +122,43 @@ __device__ __forceinline__ int bracket(const double *xt, int n, double x) {
 constexpr int PREP_AXIS_MAX = 1024;
 constexpr int PREP_ZERO_BLOCKS = 32;  // blocks per output array cleared by the prep launch
 
-// source layer for interpolation: j, or j-1 when (j-1,j) is a reusable pair (types.f90:621-632)
+// source layer for interpolation: j, or j-1 when (j-1,j) is a reusable pair (types.f90:621-632).
+// Every operand is loaded before the first comparison and the predicates are and-ed without
+// short circuit, so the ~20 loads of a layer overlap instead of forming a chain of misses (the
+// column has just arrived by DMA: nothing of it is in a cache yet).
 __device__ __forceinline__ int reuse_source(const PrepParams &p, int j) {
   const int nz = p.nz;
   const ColumnDev &c = p.col;
   if ((nz & 1) != 0 || (j & 1) == 0) return j;
   const double tol = 1.0e-12;
-  bool ok = is_close(c.P[j], c.P[j - 1], tol) && is_close(c.T[j], c.T[j - 1], tol);
+  const double Pj = c.P[j], Pm = c.P[j - 1], Tj = c.T[j], Tm = c.T[j - 1];
   const double dzj = c.dz[j], dzm = c.dz[j - 1];
-  for (int i = 0; i < p.nsp; i++) ok = ok && is_close(c.dens[i * nz + j] * dzj, c.dens[i * nz + j - 1] * dzm, tol);
-  if (p.check_radii)
-    for (int i = 0; i < p.np; i++) ok = ok && is_close(c.radii[i * nz + j], c.radii[i * nz + j - 1], tol);
+  bool ok = true;
+  for (int i0 = 0; i0 < p.nsp; i0 += 8) {
+    double a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {  // past the last species: the last one again (same predicate)
+      const int i = min(i0 + k, p.nsp - 1);
+      a[k] = c.dens[i * nz + j];
+      b[k] = c.dens[i * nz + j - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) ok = ok & is_close(a[k] * dzj, b[k] * dzm, tol);
+  }
+  if (p.check_radii) {
+    for (int i0 = 0; i0 < p.np; i0 += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = min(i0 + k, p.np - 1);
+        a[k] = c.radii[i * nz + j];
+        b[k] = c.radii[i * nz + j - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) ok = ok & is_close(a[k], b[k], tol);
+    }
+  }
+  ok = ok & is_close(Pj, Pm, tol) & is_close(Tj, Tm, tol);
   return ok ? j - 1 : j;
 }
 
@@ -142,15 +168,26 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
   const ColumnDev &c = p.col;
   if (blockIdx.x == 0) {
     for (int j = threadIdx.x; j < nz; j += blockDim.x) {
-      c.log10P[j] = log10(c.P[j]);  // types.f90:605
+      const double Pj = c.P[j], dzj = c.dz[j];
+      const int src = reuse_source(p, j);
       double fc = 0.0;
-      for (int i = 0; i < p.nsp; i++) {  // :607-619
-        const double col = c.dens[i * nz + j] * c.dz[j];
-        c.cols[i * nz + j] = col;
-        if (p.has_cont && i != p.LH2O) fc = fc + col;
+      for (int i0 = 0; i0 < p.nsp; i0 += 8) {  // :607-619, loads of a batch issued together
+        double d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = c.dens[min(i0 + k, p.nsp - 1) * nz + j];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int i = i0 + k;
+          if (i < p.nsp) {
+            const double col = d[k] * dzj;
+            c.cols[i * nz + j] = col;
+            if (p.has_cont && i != p.LH2O) fc = fc + col;
+          }
+        }
       }
+      c.log10P[j] = log10(Pj);  // types.f90:605
       c.foreign_col[j] = fc;
-      c.src[j] = reuse_source(p, j);
+      c.src[j] = src;
     }
     return;
   }
@@ -190,11 +227,14 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
   const bool in_lds = sl.n <= PREP_AXIS_MAX;
   if (in_lds)
     for (int i = threadIdx.x; i < sl.n; i += blockDim.x) s_axis[i] = sl.axis[i];
+  // the first layer's source is looked up while the axis loads are in flight
+  // custom optical properties are evaluated for every layer itself (types.f90:564-569)
+  int js_first = threadIdx.x;
+  if ((int)threadIdx.x < nz && sl.source >= 0) js_first = reuse_source(p, threadIdx.x);
   __syncthreads();
   const double *axis = in_lds ? s_axis : sl.axis;
   for (int j = threadIdx.x; j < nz; j += blockDim.x) {
-    // custom optical properties are evaluated for every layer itself (types.f90:564-569)
-    const int js = sl.source < 0 ? j : reuse_source(p, j);
+    const int js = j == (int)threadIdx.x ? js_first : (sl.source < 0 ? j : reuse_source(p, j));
     double x;
     if (sl.source < 0) x = log10(c.P[js] * 1.0e6);  // log10P_cgs, types.f90:606
     else if (sl.source == 0) x = log10(c.P[js]);
@@ -2227,7 +2267,10 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
 // in two deterministic stages (chunks of INT_CHUNK bins in bin order, then the chunk
 // sums in order), then f_total (clima_radtran.f90:316)
 // ------------------------------------------------------------------------------------
-constexpr int INT_CHUNK = 32;
+#ifndef CLIMA_INT_CHUNK
+#define CLIMA_INT_CHUNK 32
+#endif
+constexpr int INT_CHUNK = CLIMA_INT_CHUNK;
 
 __global__ __launch_bounds__(256) void k_integrate_partial(IntegrateParams p) {
   const int nl = p.nz + 1;
@@ -2307,64 +2350,73 @@ void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t
 
 int integrate_chunks(int nbins) { return nbins <= 0 ? 1 : (nbins + INT_CHUNK - 1) / INT_CHUNK; }
 
-// Both stages in one launch: a block owns INT_LV consecutive levels of all four arrays; thread
-// (level, array, chunk group) forms the chunk sums exactly as k_integrate_partial does, the chunk
-// sums meet in LDS and are added in chunk order, then f_total.  Same association as the
-// two-launch form, one launch less on the critical path of a call.
-constexpr int INT_LV = 4;   // levels per block: 51 blocks at nz = 200 (8 gave 26 blocks and 0.7 us more per call)
-constexpr int INT_CG = 32;  // chunk groups per array: threads = INT_LV * 4 * INT_CG = 512
+// Both stages in one launch: block (level group, array) owns INT_LV = 16 consecutive levels
+// (one 128-byte line per bin) of ONE of the four arrays; thread (level, chunk group) forms the
+// chunk sums exactly as k_integrate_partial does, with the frequency widths staged in LDS once
+// per block; the chunk sums meet in LDS and are added in chunk order.  Same association as the
+// two-launch form.  f_total is NOT formed here (its four operands sit in four blocks): the host
+// forms it from the four rows it fetches anyway (fetch_small), with the same expression.
+// The earlier form (4 levels x 4 arrays per block) spent its time in the L1's tag lookups:
+// every wave load touched 16 lines for 32 bytes each, and the widths were re-read per lane.
+#ifndef CLIMA_INT_LV
+#define CLIMA_INT_LV 16
+#endif
+#ifndef CLIMA_INT_CG
+#define CLIMA_INT_CG 32
+#endif
+constexpr int INT_LV = CLIMA_INT_LV;   // levels per block: 13 x 4 blocks at nz = 200
+constexpr int INT_CG = CLIMA_INT_CG;   // chunk groups: threads = INT_LV * INT_CG = 512
 
-__global__ __launch_bounds__(INT_LV * 4 * INT_CG) void k_integrate_one(IntegrateParams p) {
-  extern __shared__ __align__(16) double s_part[];  // [4][nchunk][INT_LV], then [4][INT_LV] totals
-  const int nl = p.nz + 1;
-  const int lv = threadIdx.x % INT_LV;
-  const int grp = threadIdx.x / INT_LV;
-  const int a = grp / INT_CG, cg = grp % INT_CG;
-  const int i = blockIdx.x * INT_LV + lv;
+__global__ __launch_bounds__(INT_LV * INT_CG) void k_integrate_one(IntegrateParams p) {
+  extern __shared__ __align__(16) double s_int[];  // widths [nchunk*INT_CHUNK], then partial [nchunk][INT_LV]
+  const int a = blockIdx.y;
   const bool sol = a >= 2;
-  const bool active = !(sol && !p.do_solar);
+  if (sol && !p.do_solar) return;  // solar rows keep the last solar call's values (clima_radtran.f90:286-289)
+  const int nl = p.nz + 1;
+  const int lv = threadIdx.x % INT_LV, cg = threadIdx.x / INT_LV;
+  const int i = blockIdx.x * INT_LV + lv;
   const double *src = a == 0 ? p.ir_fup_a : a == 1 ? p.ir_fdn_a : a == 2 ? p.sol_fup_a : p.sol_fdn_a;
   const double *freq = sol ? p.sol_freq : p.ir_freq;
   const int lo = sol ? p.sol_lo : p.ir_lo, cnt = sol ? p.sol_n : p.ir_n;
-  if (active && i < nl) {
-    for (int ch = cg; ch < p.nchunk; ch += INT_CG) {
-      const int l0 = lo + ch * INT_CHUNK;
-      const int l1 = min(lo + cnt, l0 + INT_CHUNK);
-      double acc = 0.0;
-      if (l0 < l1) {
-        double v[INT_CHUNK];
+  double *s_df = s_int;
+  double *s_part = s_int + (size_t)p.nchunk * INT_CHUNK;
+  // first chunk's loads go out before the widths are staged
+  double v[INT_CHUNK];
+  {
+    const int l0 = lo + cg * INT_CHUNK;
 #pragma unroll
-        for (int k = 0; k < INT_CHUNK; k++) v[k] = (l0 + k < l1) ? src[(size_t)(l0 + k) * nl + i] : 0.0;
+    for (int k = 0; k < INT_CHUNK; k++)
+      v[k] = (cg < p.nchunk && i < nl && l0 + k < lo + cnt) ? src[(size_t)(l0 + k) * nl + i] : 0.0;
+  }
+  for (int k = threadIdx.x; k < p.nchunk * INT_CHUNK; k += blockDim.x)
+    s_df[k] = k < cnt ? freq[lo + k] - freq[lo + k + 1] : 0.0;
+  __syncthreads();
+  for (int ch = cg; ch < p.nchunk; ch += INT_CG) {
+    const int l0 = lo + ch * INT_CHUNK;
+    if (ch != cg) {
 #pragma unroll
-        for (int k = 0; k < INT_CHUNK; k++)
-          if (l0 + k < l1) acc = __builtin_fma(v[k], freq[l0 + k] - freq[l0 + k + 1], acc);
-      }
-      s_part[((size_t)a * p.nchunk + ch) * INT_LV + lv] = acc;
+      for (int k = 0; k < INT_CHUNK; k++)
+        v[k] = (i < nl && l0 + k < lo + cnt) ? src[(size_t)(l0 + k) * nl + i] : 0.0;
     }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < INT_CHUNK; k++)
+      if (l0 + k < lo + cnt) acc = __builtin_fma(v[k], s_df[ch * INT_CHUNK + k], acc);
+    s_part[ch * INT_LV + lv] = acc;
   }
   __syncthreads();
-  double *s_tot = s_part + (size_t)4 * p.nchunk * INT_LV;
   if (cg == 0 && i < nl) {
-    double acc;
-    if (active) {
-      acc = 0.0;
-      for (int k = 0; k < p.nchunk; k++) acc = acc + s_part[((size_t)a * p.nchunk + k) * INT_LV + lv];
-      p.flux_n[a * nl + i] = acc;
-    } else {
-      acc = p.flux_n[a * nl + i];  // solar rows of the last solar call (clima_radtran.f90:286-289)
-    }
-    s_tot[a * INT_LV + lv] = acc;
+    double acc = 0.0;
+    for (int k = 0; k < p.nchunk; k++) acc = acc + s_part[k * INT_LV + lv];
+    p.flux_n[a * nl + i] = acc;
   }
-  __syncthreads();
-  if (p.f_total && grp == 0 && i < nl)
-    p.f_total[i] = (s_tot[3 * INT_LV + lv] - s_tot[2 * INT_LV + lv]) + (s_tot[1 * INT_LV + lv] - s_tot[0 * INT_LV + lv]);
 }
 
 void launch_integrate(const IntegrateParams &p, hipStream_t s) {
   const int nl = p.nz + 1;
-  const size_t lds = sizeof(double) * ((size_t)4 * p.nchunk * INT_LV + 4 * INT_LV);
+  const size_t lds = sizeof(double) * (size_t)p.nchunk * (INT_CHUNK + INT_LV);
   if (lds <= 64 * 1024) {
-    hipLaunchKernelGGL(k_integrate_one, dim3((nl + INT_LV - 1) / INT_LV), dim3(INT_LV * 4 * INT_CG), lds, s, p);
+    hipLaunchKernelGGL(k_integrate_one, dim3((nl + INT_LV - 1) / INT_LV, 4), dim3(INT_LV * INT_CG), lds, s, p);
     return;
   }
   hipLaunchKernelGGL(k_integrate_partial, dim3(p.nchunk, 4), dim3(256), 0, s, p);

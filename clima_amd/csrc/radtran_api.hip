@@ -537,6 +537,10 @@ void fetch_small(Radtran *r) {
   HIPCHK(hipMemcpyAsync(r->h_small, r->d_small.p, sizeof(double) * (5 * nl + 1), hipMemcpyDeviceToHost, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   resolve_events(r);
+  // f_total from the four level rows (clima_radtran.f90:287); the one-launch integration leaves it
+  // to the host, the other forms computed the same expression on the device
+  double *h = r->h_small;
+  for (int i = 0; i < nl; i++) h[4 * nl + i] = (h[3 * nl + i] - h[2 * nl + i]) + (h[1 * nl + i] - h[0 * nl + i]);
   r->small_valid = true;
 }
 
@@ -1181,7 +1185,6 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
   HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, sizeof(int), hipMemcpyDeviceToHost, r->stream));
   // the handle's own level fluxes = the last column's
   HIPCHK(hipMemcpyAsync(r->d_flux_n.p, r->d_flux_arena.p + (size_t)(n - 1) * 5 * nl, sizeof(double) * 4 * nl, hipMemcpyDeviceToDevice, r->stream));
-  HIPCHK(hipMemcpyAsync(r->d_f_total.p, r->d_flux_arena.p + (size_t)(n - 1) * 5 * nl + 4 * nl, sizeof(double) * nl, hipMemcpyDeviceToDevice, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   resolve_events(r);
   r->small_valid = false;
@@ -1193,7 +1196,8 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
   }
   r->checked_id = r->call_id;
   for (int c = 0; c < n; c++) {
-    const double *f = out.data() + (size_t)c * 5 * nl;
+    double *f = out.data() + (size_t)c * 5 * nl;
+    for (int i = 0; i < nl; i++) f[4 * nl + i] = (f[3 * nl + i] - f[2 * nl + i]) + (f[1 * nl + i] - f[0 * nl + i]);  // :287
     ISR[c] = f[3 * nl + nz] - f[2 * nl + nz];        // clima_radtran.f90:339-340
     OLR[c] = -(f[1 * nl + nz] - f[0 * nl + nz]);
     if (fluxes) std::memcpy(fluxes + (size_t)c * 5 * nl, f, sizeof(double) * 5 * nl);

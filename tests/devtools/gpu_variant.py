@@ -33,6 +33,6 @@ r.profile(True); r.profile_reset()
 for _ in range(50): r.radiate_resident()
 r.synchronize()
 ks = [r.kernel_time(i) for i in range(4)]
-print("%s: %.1f us/call (best of 3x%d) | opacity %.1f twostream %.1f us | OLR rel %.1e ISR rel %.1e opr rel %s" % (
-    name, best * 1e6, reps, 1e3 * ks[1][0] / max(ks[1][1], 1), 1e3 * ks[2][0] / max(ks[2][1], 1),
+print("%s: %.1f us/call (best of 3x%d) | prep %.2f integrate %.2f | opacity %.1f twostream %.1f us | OLR rel %.1e ISR rel %.1e opr rel %s" % (
+    name, best * 1e6, reps, 1e3 * ks[0][0] / max(ks[0][1], 1), 1e3 * ks[3][0] / max(ks[3][1], 1), 1e3 * ks[1][0] / max(ks[1][1], 1), 1e3 * ks[2][0] / max(ks[2][1], 1),
     abs(olr - olr_o) / abs(olr_o), abs(isr - isr_o) / abs(isr_o), " ".join("%.1e" % x for x in opr)))
