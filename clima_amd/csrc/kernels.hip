@@ -60,8 +60,8 @@ __device__ __forceinline__ double rcp_nr(double x) {
 
 // exp(x) in ~20 f64 instructions (the ocml exp is ~2x that): k = rint(x*log2e),
 // r = x - k*ln2 (two-term Cody-Waite), degree-13 Taylor polynomial in r (|r| <= 0.35,
-// truncation 5e-18), scaled by 2^k.  Error <= 1 ulp over the arguments of this path;
-// underflows to 0 like exp().  tests/test_gpu_parity.py::test_device_exp checks it.
+// truncation 5e-18), scaled by 2^k (two v_ldexp_f64).  Error <= 1 ulp over the arguments of this
+// path; underflows to 0 like exp().  tests/test_gpu_parity.py::test_device_exp checks it.
 __device__ __forceinline__ double fast_exp(double x) {
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
@@ -80,12 +80,12 @@ __device__ __forceinline__ double fast_exp(double x) {
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  // scale by 2^k in two exact steps (2^k alone overflows before p*2^k does near exp's limit)
-  const int ki = (int)__builtin_fmin(__builtin_fmax(k, -2000.0), 2000.0);
-  const int k1 = ki >> 1, k2 = ki - k1;
-  const double s1 = __longlong_as_double((long long)(k1 + 1023) << 52);
-  const double s2 = __longlong_as_double((long long)(k2 + 1023) << 52);
-  return (p * s1) * s2;
+  // scale by 2^k with v_ldexp_f64, in two steps because it returns inf for an exponent argument of
+  // 1024 even where p*2^1024 is representable (p < 1); both steps are exact (or round once, into
+  // the subnormals).  The convert saturates, so huge |x| end in 0 / inf as they should.
+  const int ki = (int)k;
+  const int kk = min(ki, 1023);
+  return __builtin_ldexp(__builtin_ldexp(p, kk), ki - kk);
 }
 
 // ten2power, src/clima_eqns.f90:75-80
@@ -133,7 +133,7 @@ __device__ __forceinline__ int reuse_source(const PrepParams &p, int j) {
   const double tol = 1.0e-12;
   const double Pj = c.P[j], Pm = c.P[j - 1], Tj = c.T[j], Tm = c.T[j - 1];
   const double dzj = c.dz[j], dzm = c.dz[j - 1];
-  bool ok = true;
+  int ok = 1;  // and-ed as integers: no short circuit
   for (int i0 = 0; i0 < p.nsp; i0 += 8) {
     double a[8], b[8];
 #pragma unroll
@@ -143,7 +143,7 @@ __device__ __forceinline__ int reuse_source(const PrepParams &p, int j) {
       b[k] = c.dens[i * nz + j - 1];
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) ok = ok & is_close(a[k] * dzj, b[k] * dzm, tol);
+    for (int k = 0; k < 8; k++) ok &= (int)is_close(a[k] * dzj, b[k] * dzm, tol);
   }
   if (p.check_radii) {
     for (int i0 = 0; i0 < p.np; i0 += 4) {
@@ -155,10 +155,11 @@ __device__ __forceinline__ int reuse_source(const PrepParams &p, int j) {
         b[k] = c.radii[i * nz + j - 1];
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) ok = ok & is_close(a[k], b[k], tol);
+      for (int k = 0; k < 4; k++) ok &= (int)is_close(a[k], b[k], tol);
     }
   }
-  ok = ok & is_close(Pj, Pm, tol) & is_close(Tj, Tm, tol);
+  ok &= (int)is_close(Pj, Pm, tol);
+  ok &= (int)is_close(Tj, Tm, tol);
   return ok ? j - 1 : j;
 }
 
@@ -1393,7 +1394,18 @@ constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
 
 template <int LMAX, bool SOLAR, bool COHERENT, int NZMAX>
 __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const int bin_local, double *lds,
-                                                 const int gy, const int bz) {
+                                                 const int gy, const int bz, const int tslot = -1) {
+#ifdef CLIMA_STAMPS
+#define TSTAMP(k)                                                                                  \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (tslot >= 0 && g_stamp_buf && threadIdx.x == 0) g_stamp_buf[tslot + (k)] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+  TSTAMP(0);
   const int nz = p.nz, ng = p.ng, nl = nz + 1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr bool solar = SOLAR;
@@ -1442,6 +1454,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
   } else {
     Rsfc = p.has_hard_surface ? 1.0 - p.emissivity[ll] : 0.0;  // :186-190
   }
+  TSTAMP(1);
   const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64 (IR)
   // batched shared-opacity IR launches: blockIdx.z selects the temperature column (strides 0 otherwise)
   const double *Tcol = p.T + (size_t)bz * p.b_T;
@@ -1595,6 +1608,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
       }
     }
   }
+  TSTAMP(2);
   // ---- upward: y_r = alpha_r + beta_r*Uin + gamma_r*Din   (alpha -> rd, beta -> rc, gamma -> rl)
   double aB0 = 0, bB0 = 0, gB0 = 0, aB1 = 0, bB1 = 0, gB1 = 0;
   {
@@ -1623,6 +1637,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
     uS = rd[0] * ea.e3 - rd[1] * ea.e4 + cp0_top; uD = rl[0] * ea.e3 - rl[1] * ea.e4; uU = rc[0] * ea.e3 - rc[1] * ea.e4;
     dS = aB0 * eb.e3 + aB1 * eb.e4 + cmbb; dD = gB0 * eb.e3 + gB1 * eb.e4; dU = bB0 * eb.e3 + bB1 * eb.e4;
   }
+  TSTAMP(3);
   // ---- bottom-up suffix scan of the projective reflectance recursion
   M7 P;
   P.m00 = uU * dD - uD * dU; P.m02 = uD; P.m10 = uU * dS - uS * dU; P.m11 = uU; P.m12 = uS; P.m20 = -dU; P.m22 = 1.0;
@@ -1631,6 +1646,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
     const M7 R = m7_shfl_down(P, d);
     if (lane + d < 64) P = m7_mul(P, R);
   }
+  TSTAMP(4);
   // P applied to (0,0,1): state above chunk `lane`; the state below it lives one lane down
   const double rinv = rcp_nr(P.m22);
   const double rho_above = P.m02 * rinv, sig_above = P.m12 * rinv;
@@ -1649,6 +1665,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
   if (lane == 0) Din = 0.0;
   const double Uin = mm * (rho * dS + sig + rho * dD * Din);
 
+  TSTAMP(5);
   // ---- level fluxes (:143-148, :288-293), mean intensity (:135-140), g-point weight
   double *sFu = lds + (size_t)(0 * TSW_COLS + wave) * nl;
   double *sFd = lds + (size_t)(1 * TSW_COLS + wave) * nl;
@@ -1671,7 +1688,9 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
       }
     }
   }
+  TSTAMP(6);
   __syncthreads();
+  TSTAMP(7);
   // ---- sum over the block's g-points, unit factors (radiate.f90:167-180), reversal (:140-154)
   const bool split = p.accumulate != 0;
   double scale = 1.0;
@@ -1703,6 +1722,8 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
     double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
     for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = ld_opr<COHERENT>(&p.tau_band[(size_t)l * nz + (nz - 1 - i)]);
   }
+  TSTAMP(8);
+#undef TSTAMP
 }
 
 // one launch for both channels: blocks [0, n_sol) are solar bins (the heavier ones first),
@@ -2216,6 +2237,9 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   const int ll = solar ? ts.sol_lo + bl : ts.ir_lo + (bl - ts.n_sol);
   const int l = (solar ? ts.sol_start : ts.ir_start) + ll;
   __shared__ int s_ok;
+#ifdef CLIMA_STAMPS
+  if (op.stamps && threadIdx.x == 0) op.stamps[64 + 2 * 3128 + 3 * b] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (threadIdx.x == 0) {
     const long t0 = (long)(l - op.bin_lo) * op.nz;
     const int d0 = max((int)(t0 / OP_THREADS), 0), d1 = min((int)((t0 + op.nz - 1) / OP_THREADS), fp.n_op - 1);
@@ -2232,8 +2256,20 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   }
   __syncthreads();
   if (!s_ok) return;
-  if (solar) twostream_w_body<4, true, true, FUSED_NZMAX>(ts, bl, lds, gy, 0);
-  else twostream_w_body<4, false, true, 0>(ts, bl - ts.n_sol, lds, gy, 0);
+#ifdef CLIMA_STAMPS
+  if (op.stamps && threadIdx.x == 0) op.stamps[64 + 2 * 3128 + 3 * b + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef CLIMA_STAMPS
+  const int tslot = (b == 1500) ? 32 : (b == 2200 ? 48 : -1);  // a solar and an IR block of the two-stream-only tail
+#else
+  const int tslot = -1;
+#endif
+  if (solar) twostream_w_body<4, true, true, FUSED_NZMAX>(ts, bl, lds, gy, 0, tslot);
+  else twostream_w_body<4, false, true, 0>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
+#ifdef CLIMA_STAMPS
+  __syncthreads();
+  if (op.stamps && threadIdx.x == 0) op.stamps[64 + 2 * 3128 + 3 * b + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // false when the configuration is outside what the fused form covers (the caller then uses the

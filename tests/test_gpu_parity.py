@@ -77,7 +77,7 @@ def test_device_exp(hip_lib):
     import ctypes as C
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.uniform(-760, 5, 200000), rng.uniform(-1e-3, 1e-3, 1000), -10 ** rng.uniform(-12, 7, 2000),
-                        rng.uniform(600, 720, 1000), [0.0, -0.0, -745.2, -1e9, 709.7, 710.5]])
+                        rng.uniform(600, 720, 1000), [0.0, -0.0, -745.2, -1e9, 709.7, 710.5, 709.78, 709.1, 1e6, -1e6, 5e9, -5e9, 1e14, -1e14]])
     y = np.empty_like(x)
     err = C.create_string_buffer(1025)
     dp = C.POINTER(C.c_double)
