@@ -58,10 +58,18 @@ __device__ __forceinline__ double rcp_nr(double x) {
   return r;
 }
 
-// exp(x) in ~20 f64 instructions (the ocml exp is ~2x that): k = rint(x*log2e),
+// exp(x) in ~23 f64 operations (the ocml exp is ~2x that): k = rint(x*log2e),
 // r = x - k*ln2 (two-term Cody-Waite), degree-13 Taylor polynomial in r (|r| <= 0.35,
 // truncation 5e-18), scaled by 2^k (two v_ldexp_f64).  Error <= 1 ulp over the arguments of this
 // path; underflows to 0 like exp().  tests/test_gpu_parity.py::test_device_exp checks it.
+__device__ __forceinline__ double exp_scale(double p, double k) {
+  // scale by 2^k with v_ldexp_f64, in two steps because it returns inf for an exponent argument of
+  // 1024 even where p*2^1024 is representable (p < 1); both steps are exact (or round once, into
+  // the subnormals).  The convert saturates, so huge |x| end in 0 / inf as they should.
+  const int ki = (int)k;
+  const int kk = min(ki, 1023);
+  return __builtin_ldexp(__builtin_ldexp(p, kk), ki - kk);
+}
 __device__ __forceinline__ double fast_exp(double x) {
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
@@ -80,18 +88,63 @@ __device__ __forceinline__ double fast_exp(double x) {
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  // scale by 2^k with v_ldexp_f64, in two steps because it returns inf for an exponent argument of
-  // 1024 even where p*2^1024 is representable (p < 1); both steps are exact (or round once, into
-  // the subnormals).  The convert saturates, so huge |x| end in 0 / inf as they should.
-  const int ki = (int)k;
-  const int kk = min(ki, 1023);
-  return __builtin_ldexp(__builtin_ldexp(p, kk), ki - kk);
+  return exp_scale(p, k);
+}
+
+// The same exp with its 14 non-inline constants held in VGPRs by the caller (ExpK::load() makes
+// them opaque, so hipcc cannot fall back to materialising them again).  With literal constants every
+// Horner step compiles to "two v_mov_b32 (or one v_mov_b64) of the constant into the destination,
+// then v_fmac_f64": 2-3 instructions where the three-address v_fma_f64 below needs one.  A wave
+// of this code issues roughly one instruction per 9-10 cycles whatever its type, so it is the
+// instruction count of the wave, not the VALU's, that sets its run time.  Same operations, same
+// rounding: results are bitwise those of fast_exp().
+struct ExpK {
+  double l2e, ln2h, ln2l, c[11];
+  __device__ __forceinline__ void load() {
+    const double v[14] = {1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
+                          1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08,
+                          2.755731922398589e-07, 2.7557319223985893e-06, 2.48015873015873e-05,
+                          1.984126984126984e-04, 1.388888888888889e-03, 8.333333333333333e-03,
+                          4.1666666666666664e-02, 1.6666666666666666e-01};
+    l2e = v[0]; ln2h = v[1]; ln2l = v[2];
+    asm volatile("" : "+v"(l2e), "+v"(ln2h), "+v"(ln2l));
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+      c[i] = v[3 + i];
+      asm volatile("" : "+v"(c[i]));
+    }
+  }
+};
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+#ifdef CLIMA_FMA3_ASM
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+#else
+  return __builtin_fma(a, b, c);
+#endif
+}
+__device__ __forceinline__ double fast_exp(double x, const ExpK &K) {
+  const double k = __builtin_rint(x * K.l2e);
+  double r = fma3(k, K.ln2h, x);
+  r = fma3(k, K.ln2l, r);
+  double p = fma3(K.c[0], r, K.c[1]);
+#pragma unroll
+  for (int i = 2; i < 11; i++) p = fma3(p, r, K.c[i]);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return exp_scale(p, k);
 }
 
 // ten2power, src/clima_eqns.f90:75-80
 __device__ __forceinline__ double ten2power(double y) { return fast_exp(y * LN10); }
 
 // planck_fcn, src/clima_eqns.f90:64-73
+__device__ __forceinline__ double planck_fcn(double nu, double T, const ExpK &K) {
+  return 1.0e3 * ((2.0 * PLANK * (nu * nu * nu)) / (C_LIGHT * C_LIGHT)) *
+         ((1.0) / (fast_exp((PLANK * nu) / (K_BOLTZ_SI * T), K) - 1.0));
+}
 __device__ __forceinline__ double planck_fcn(double nu, double T) {
   return 1.0e3 * ((2.0 * PLANK * (nu * nu * nu)) / (C_LIGHT * C_LIGHT)) *
          ((1.0) / (fast_exp((PLANK * nu) / (K_BOLTZ_SI * T)) - 1.0));
@@ -1406,6 +1459,18 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 #define TSTAMP(k) do { } while (0)
 #endif
   TSTAMP(0);
+  // exp with its constants resident in VGPRs where the register budget is there anyway (the
+  // fused grid: 256 per wave); the stand-alone kernel keeps three waves per SIMD instead
+  ExpK K;
+  if constexpr (COHERENT) K.load();
+  auto fexp = [&](double x) {
+    if constexpr (COHERENT) return fast_exp(x, K);
+    else return fast_exp(x);
+  };
+  auto planck = [&](double nu, double T) {
+    if constexpr (COHERENT) return planck_fcn(nu, T, K);
+    else return planck_fcn(nu, T);
+  };
   const int nz = p.nz, ng = p.ng, nl = nz + 1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr bool solar = SOLAR;
@@ -1477,7 +1542,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 #pragma unroll
     for (int z = 0; z < NZMAX; z++) etc[z] = 1.0;
     if constexpr (!solar)
-      if (len > 0) bpl_top = planck_fcn(avg_freq, a == nz ? *Tsfc : Tcol[nz - 1 - a]);
+      if (len > 0) bpl_top = planck(avg_freq, a == nz ? *Tsfc : Tcol[nz - 1 - a]);
 #pragma unroll
     for (int t = 0; t < LMAX; t++) {
       G[t] = X[t] = cpb[t] = cmb[t] = dir[t] = diru[t] = 0.0;
@@ -1495,7 +1560,7 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
           const double gam2 = sqrt3 * w0p * (1.0 - gtp) / 2.0;
           const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
           G[t] = gam2 / (gam1 + lam);
-          X[t] = fast_exp(-lam * taup);  // :56
+          X[t] = fexp(-lam * taup);  // :56
           const double tauc = tcum;
           tcum = tcum + taup;
           // C+/C- and direct beam (:73-87) summed over the zenith angles with their weights
@@ -1512,8 +1577,8 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
               const double facm = w0p * ((gam1 + iu) * gam4 + gam2 * gam3);
               // exp(-tauc/u0) at the top of the layer (:78): computed for the chunk's first
               // layer, afterwards carried from the layer above (etb there is the same quantity)
-              const double et0 = (t == 0) ? fast_exp(-tauc * iu) : etc[z];
-              const double etb = et0 * fast_exp(-taup * iu);  // :79
+              const double et0 = (t == 0) ? fexp(-tauc * iu) : etc[z];
+              const double etb = et0 * fexp(-taup * iu);  // :79
               etc[z] = etb;
               const double rden = wz * rcp_nr(lam2 - iu * iu);  // w_z / denom (:80)
               const double fp = facp * rden, fm = facm * rden;
@@ -1531,8 +1596,8 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
             const double gam4 = 1.0 - gam3;
             const double facp = w0p * ((gam1 - iu) * gam3 + gam4 * gam2);
             const double facm = w0p * ((gam1 + iu) * gam4 + gam2 * gam3);
-            const double et0 = fast_exp(-tauc * iu);
-            const double etb = et0 * fast_exp(-taup * iu);
+            const double et0 = fexp(-tauc * iu);
+            const double etb = et0 * fexp(-taup * iu);
             const double rden = wz * rcp_nr(lam2 - iu * iu);
             const double fp = facp * rden, fm = facm * rden;
             CP0 = __builtin_fma(et0, fp, CP0);
@@ -1549,8 +1614,8 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
           const double gam2 = w0_in * (1.0 - gt_in);
           const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
           G[t] = gam2 / (gam1 + lam);
-          X[t] = fast_exp(-lam * tau_in);
-          const double bpl_bot = planck_fcn(avg_freq, i + 1 == nz ? *Tsfc : Tcol[nz - 2 - i]);  // radiate.f90:65-69
+          X[t] = fexp(-lam * tau_in);
+          const double bpl_bot = planck(avg_freq, i + 1 == nz ? *Tsfc : Tcol[nz - 2 - i]);  // radiate.f90:65-69
           double b0n, b1n;  // :216-227
           if (tau_in <= p.ir_tau_min) {
             b0n = 0.5 * (bpl_top + bpl_bot);
