@@ -1567,28 +1567,35 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
           // (the matrix does not depend on u0: sum_z w_z*solve(E_z) == solve(sum_z w_z*E_z))
           const double lam2 = lam * lam;
           double CP0 = 0.0, CPB = 0.0, CM0 = 0.0, CMB = 0.0, DIR = 0.0, DIRU = 0.0;
+          auto zen = [&](const int z) {
+            const double u0 = p.zen_u_v[z], wz = p.zen_w_v[z], iu = p.zen_iu_v[z];
+            const double gam3 = (1.0 - sqrt3 * gtp * u0) / 2.0;
+            const double gam4 = 1.0 - gam3;
+            const double facp = w0p * ((gam1 - iu) * gam3 + gam4 * gam2);
+            const double facm = w0p * ((gam1 + iu) * gam4 + gam2 * gam3);
+            // exp(-tauc/u0) at the top of the layer (:78): computed for the chunk's first
+            // layer, afterwards carried from the layer above (etb there is the same quantity)
+            const double et0 = (t == 0) ? fexp(-tauc * iu) : etc[z];
+            const double etb = et0 * fexp(-taup * iu);  // :79
+            etc[z] = etb;
+            const double rden = wz * rcp_nr(lam2 - iu * iu);  // w_z / denom (:80)
+            const double fp = facp * rden, fm = facm * rden;
+            CP0 = __builtin_fma(et0, fp, CP0);
+            CPB = __builtin_fma(etb, fp, CPB);
+            CM0 = __builtin_fma(et0, fm, CM0);
+            CMB = __builtin_fma(etb, fm, CMB);
+            DIR = __builtin_fma(wz * u0, etb, DIR);   // direct(i+1) = u0*etb (:82)
+            DIRU = __builtin_fma(wz, etb, DIRU);      // direct(i+1)/u0
+          };
+          // all NZMAX carried angles present (the usual case): one straight-line block, so their
+          // constant loads batch and their chains interleave; otherwise angle by angle
+          if (NZMAX > 0 && p.nzen >= NZMAX) {
 #pragma unroll
-          for (int z = 0; z < NZMAX; z++) {
-            if (z < p.nzen) {
-              const double u0 = p.zen_u_v[z], wz = p.zen_w_v[z], iu = p.zen_iu_v[z];
-              const double gam3 = (1.0 - sqrt3 * gtp * u0) / 2.0;
-              const double gam4 = 1.0 - gam3;
-              const double facp = w0p * ((gam1 - iu) * gam3 + gam4 * gam2);
-              const double facm = w0p * ((gam1 + iu) * gam4 + gam2 * gam3);
-              // exp(-tauc/u0) at the top of the layer (:78): computed for the chunk's first
-              // layer, afterwards carried from the layer above (etb there is the same quantity)
-              const double et0 = (t == 0) ? fexp(-tauc * iu) : etc[z];
-              const double etb = et0 * fexp(-taup * iu);  // :79
-              etc[z] = etb;
-              const double rden = wz * rcp_nr(lam2 - iu * iu);  // w_z / denom (:80)
-              const double fp = facp * rden, fm = facm * rden;
-              CP0 = __builtin_fma(et0, fp, CP0);
-              CPB = __builtin_fma(etb, fp, CPB);
-              CM0 = __builtin_fma(et0, fm, CM0);
-              CMB = __builtin_fma(etb, fm, CMB);
-              DIR = __builtin_fma(wz * u0, etb, DIR);   // direct(i+1) = u0*etb (:82)
-              DIRU = __builtin_fma(wz, etb, DIRU);      // direct(i+1)/u0
-            }
+            for (int z = 0; z < NZMAX; z++) zen(z);
+          } else {
+#pragma unroll
+            for (int z = 0; z < NZMAX; z++)
+              if (z < p.nzen) zen(z);
           }
           for (int z = NZMAX; z < p.nzen; z++) {  // more zenith angles than the carried set: recompute
             const double u0 = p.zen_u_v[z], wz = p.zen_w_v[z], iu = p.zen_iu_v[z];
@@ -1791,6 +1798,361 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 #undef TSTAMP
 }
 
+// ------------------------------------------------------------------------------------
+// twostream_p_body: the wave-per-column solve as straight-line code, used by k_fused.  Same
+// equations, decomposition and scans as twostream_w_body.  The difference is the lane whose chunk
+// holds fewer than L layers: its L slots are filled from the top with zero-thickness layers
+// (tau = 0, w0 = 0: transparent, and with the same Planck value on both faces they emit nothing);
+// its real layers sit below them.  A zero-thickness layer hands both fluxes through unchanged, so
+// the column's solution is the same (to rounding: its rows have pivots of 2), and every lane runs
+// the same L layers.  With no per-layer branch there are no exec-mask regions, no merge copies
+// and no zero initialisation of skipped layers, the zenith angles become the outer loop (their
+// constants are fetched once, the direct-beam transmission is a running product down the chunk)
+// and the whole coefficient phase is one block for the scheduler.  In this code a wave's run
+// time follows its instruction count (see fast_exp), and those were a third of it.
+// ------------------------------------------------------------------------------------
+template <int L, bool SOLAR, int NZMAX, bool COHERENT, bool RESK>
+__device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const int bin_local, double *lds,
+                                                 const int gy, const int bz, const int tslot = -1) {
+#ifdef CLIMA_STAMPS
+#define TSTAMP(k)                                                                                  \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (tslot >= 0 && g_stamp_buf && threadIdx.x == 0) g_stamp_buf[tslot + (k)] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+  TSTAMP(0);
+  constexpr bool solar = SOLAR;
+  // exp with its constants resident in VGPRs where the register budget is there anyway (RESK: the
+  // fused grid, 256 per wave); the stand-alone kernel keeps three waves per SIMD instead
+  ExpK K;
+  if constexpr (RESK) K.load();
+  auto fexp = [&](double x) {
+    if constexpr (RESK) return fast_exp(x, K);
+    else return fast_exp(x);
+  };
+  auto planck = [&](double nu, double T) {
+    if constexpr (RESK) return planck_fcn(nu, T, K);
+    else return planck_fcn(nu, T);
+  };
+  const int nz = p.nz, ng = p.ng, nl = nz + 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ll = (solar ? p.sol_lo : p.ir_lo) + bin_local;
+  const int l = (solar ? p.sol_start : p.ir_start) + ll;  // opacity bin (radiate.f90:57)
+  const int c_raw = p.col_base + gy * TSW_COLS + wave;
+  const bool col_on = c_raw < ng;
+  const int c = col_on ? c_raw : ng - 1;
+  const double wcol = col_on ? p.wbin[c] : 0.0;  // g-point weight (radiate.f90:122-126)
+  const double *tauL = p.tau + ((size_t)l * ng + c) * nz;
+  const double *w0L = p.w0 + ((size_t)l * ng + c) * nz;
+  const double *gL = p.g + (size_t)l * nz;
+  // layers [a,b) TOA-first; slot t holds layer a + t - pad when t >= pad, a zero-thickness layer otherwise
+  const int a = (lane * nz) >> 6, b = ((lane + 1) * nz) >> 6, pad = L - (b - a);
+  const bool is_toa = lane == 0, is_sfc = lane == 63;  // b == nz holds for lane 63 only, and its chunk is never empty
+  const double sqrt3 = 1.7320508075688772;
+  const double inv_u1 = solar ? sqrt3 : 0.0;  // 1/u1, u1 = 1/sqrt(3) (solar only)
+
+  // ---- the slots' inputs: one batch of loads (a valid address also for the zero-thickness slots)
+  double tau_s[L], w0_s[L], gt_s[L];
+#pragma unroll
+  for (int t = 0; t < L; t++) {
+    const int i = min(max(a + t - pad, 0), nz - 1);
+    tau_s[t] = ld_opr<COHERENT>(&tauL[i]);
+    w0_s[t] = ld_opr<COHERENT>(&w0L[i]);
+    gt_s[t] = ld_opr<COHERENT>(&gL[i]);
+  }
+#pragma unroll
+  for (int t = 0; t < L; t++) {
+    const bool real = t >= pad;
+    tau_s[t] = real ? tau_s[t] : 0.0;
+    w0_s[t] = real ? w0_s[t] : 0.0;
+    gt_s[t] = real ? gt_s[t] : 0.0;
+  }
+
+  double G[L], X[L], cp0[L], cm0[L], cpb[L], cmb[L], dir[L], diru[L];
+  double Rsfc, Ssfc = 0.0, lvl0_dn = 0.0, lvl0_am = 0.0;
+
+  if constexpr (solar) {
+    // ---- delta-Eddington (:38-40), quadrature coefficients (:43-44), lambda, Gamma (:50-51)
+    double taup[L], w0p[L], gtp[L], gam1[L], gam2[L], lam2[L];
+    double tot = 0.0;
+#pragma unroll
+    for (int t = 0; t < L; t++) {
+      taup[t] = tau_s[t] * (1.0 - w0_s[t] * gt_s[t] * gt_s[t]);
+      tot = tot + taup[t];
+    }
+    // optical depth above the chunk (tauc, :64-67): exclusive wave scan of the chunk totals
+    double incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double nb = __shfl_up(incl, d);
+      if (lane >= d) incl = incl + nb;
+    }
+    double tcum = __shfl_up(incl, 1);
+    if (lane == 0) tcum = 0.0;
+    double tauc[L];
+#pragma unroll
+    for (int t = 0; t < L; t++) {
+      w0p[t] = w0_s[t] * (1.0 - gt_s[t] * gt_s[t]) / (1.0 - w0_s[t] * gt_s[t] * gt_s[t]);
+      gtp[t] = gt_s[t] / (1.0 + gt_s[t]);
+      gam1[t] = sqrt3 * (2.0 - w0p[t] * (1 + gtp[t])) / 2.0;
+      gam2[t] = sqrt3 * w0p[t] * (1.0 - gtp[t]) / 2.0;
+      const double lam = sqrt(gam1[t] * gam1[t] - gam2[t] * gam2[t]);
+      G[t] = gam2[t] / (gam1[t] + lam);
+      X[t] = fexp(-lam * taup[t]);  // :56
+      // a zero-thickness slot has w0p = 0, so its C+/C- vanish whatever the denominator
+      // lam^2 - 1/u0^2 is -- as long as that is not 0 (u0 = 1/sqrt(3)): keep it away from 0
+      lam2[t] = (t >= pad) ? lam * lam : -1.0;
+      tauc[t] = tcum;
+      tcum = tcum + taup[t];
+      cp0[t] = cm0[t] = cpb[t] = cmb[t] = dir[t] = diru[t] = 0.0;
+    }
+    TSTAMP(1);
+    // ---- C+/C- and direct beam (:73-87) summed over the zenith angles with their weights (the
+    //      matrix does not depend on u0: sum_z w_z*solve(E_z) == solve(sum_z w_z*E_z)).  exp(-tauc/u0)
+    //      is evaluated at the chunk's top and carried down as a running product (:78-79).
+    double wsum = 0.0, dir0 = 0.0;
+    auto zen = [&](const int z) {
+      const double u0 = p.zen_u_v[z], wz = p.zen_w_v[z], iu = p.zen_iu_v[z];
+      wsum = wsum + wz;
+      dir0 = dir0 + wz * u0;
+      double et = fexp(-tauc[0] * iu);
+#pragma unroll
+      for (int t = 0; t < L; t++) {
+        const double gam3 = (1.0 - sqrt3 * gtp[t] * u0) / 2.0;
+        const double gam4 = 1.0 - gam3;
+        const double facp = w0p[t] * ((gam1[t] - iu) * gam3 + gam4 * gam2[t]);
+        const double facm = w0p[t] * ((gam1[t] + iu) * gam4 + gam2[t] * gam3);
+        const double etb = et * fexp(-taup[t] * iu);  // :79
+        const double rden = wz * rcp_nr(lam2[t] - iu * iu);  // w_z / denom (:80)
+        const double fp = facp * rden, fm = facm * rden;
+        cp0[t] = __builtin_fma(et, fp, cp0[t]);
+        cpb[t] = __builtin_fma(etb, fp, cpb[t]);
+        cm0[t] = __builtin_fma(et, fm, cm0[t]);
+        cmb[t] = __builtin_fma(etb, fm, cmb[t]);
+        dir[t] = __builtin_fma(wz * u0, etb, dir[t]);   // direct(i+1) = u0*etb (:82)
+        diru[t] = __builtin_fma(wz, etb, diru[t]);      // direct(i+1)/u0
+        et = etb;
+      }
+    };
+    if (NZMAX > 0 && p.nzen >= NZMAX) {  // the usual case: no per-angle test
+#pragma unroll
+      for (int z = 0; z < NZMAX; z++) zen(z);
+    } else {
+#pragma unroll
+      for (int z = 0; z < NZMAX; z++)
+        if (z < p.nzen) zen(z);
+    }
+    for (int z = NZMAX; z < p.nzen; z++) zen(z);
+    lvl0_dn = dir0;   // direct(1) = u0 (:73)
+    lvl0_am = wsum;   // direct(1)/u0 = 1
+    Rsfc = p.albedo[ll];
+    Ssfc = Rsfc * dir[L - 1];  // :89 (used by the surface row only)
+  } else {
+    Rsfc = p.has_hard_surface ? 1.0 - p.emissivity[ll] : 0.0;  // :186-190
+    const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64
+    // batched shared-opacity IR launches: blockIdx.z selects the temperature column (strides 0 otherwise)
+    const double *Tcol = p.T + (size_t)bz * p.b_T;
+    const double *Tsfc = p.T_surface + (size_t)bz * p.b_Ts;
+    // Planck at the L+1 faces of the slots (level a for every face of a zero-thickness slot)
+    double bpl[L + 1];
+#pragma unroll
+    for (int s = 0; s <= L; s++) {
+      const int n = a + max(s - pad, 0);  // TOA-first level
+      bpl[s] = planck(avg_freq, n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);  // radiate.f90:65-69
+    }
+    TSTAMP(1);
+#pragma unroll
+    for (int t = 0; t < L; t++) {
+      const double tau_in = tau_s[t], w0_in = w0_s[t], gt_in = gt_s[t];
+      const double gam1 = 2.0 - w0_in * (1.0 + gt_in);  // :195-201
+      const double gam2 = w0_in * (1.0 - gt_in);
+      const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
+      G[t] = gam2 / (gam1 + lam);
+      X[t] = fexp(-lam * tau_in);
+      const double bpl_top = bpl[t], bpl_bot = bpl[t + 1];
+      double b0n, b1n;  // :216-227
+      if (tau_in <= p.ir_tau_min) {
+        b0n = 0.5 * (bpl_top + bpl_bot);
+        b1n = 0.0;
+      } else {
+        b0n = bpl_top;
+        b1n = (bpl_bot - b0n) / tau_in;
+      }
+      const double norm = 2.0 * PI * 0.5;
+      const double r = 1.0 / (gam1 + gam2);
+      cp0[t] = norm * (b0n + b1n * (r));  // :229-232
+      cpb[t] = norm * (b0n + b1n * (tau_in + r));
+      cm0[t] = norm * (b0n + b1n * (-r));
+      cmb[t] = norm * (b0n + b1n * (tau_in - r));
+      dir[t] = diru[t] = 0.0;
+    }
+    {  // surface source (:236-247), used by the surface row only
+      const double tau_in = tau_s[L - 1], bpl_top = bpl[L - 1], bpl_bot = bpl[L];
+      if (p.has_hard_surface) {
+        Ssfc = p.emissivity[ll] * PI * bpl_bot;
+      } else {
+        const double b1_bot = (tau_in <= p.ir_tau_min) ? 0.0 : (bpl_bot - bpl_top) / tau_in;
+        Ssfc = PI * (bpl_bot + 0.5 * b1_bot);
+      }
+    }
+  }
+  TSTAMP(2);
+
+  // ---- the chunk's tridiagonal system, eliminated downward (y_r + c' y_{r+1} + l*Din = d').
+  //      Row 2t-1 couples slots t-1,t (Fortran even rows, :106-112), row 2t likewise (odd rows,
+  //      :97-103); row 0 and row 2L-1 are the flux boundary rows (TOA :93-96 / surface :113-117 at
+  //      the column ends).
+  double rc[2 * L], rd[2 * L], rl[2 * L];
+  {
+    double cp, dp, lp;
+    E4 u = make_e(G[0], X[0]);
+    {
+      // row 0: TOA row (:93-96) or the flux condition "-Din + e1 y1 - e2 y2 = -cm0"
+      const double A = is_toa ? 0.0 : -1.0;
+      const double r = rcp_nr(u.e1);
+      cp = (-u.e2) * r; dp = (0.0 - cm0[0]) * r; lp = A * r;
+      rc[0] = cp; rd[0] = dp; rl[0] = lp;
+    }
+#pragma unroll
+    for (int t = 1; t < L; t++) {
+      const E4 v = make_e(G[t], X[t]);
+      // row 2t-1 (slots t-1, t)
+      double A = v.e2 * u.e1 - u.e3 * v.e4, B = u.e2 * v.e2 - u.e4 * v.e4, D = v.e1 * v.e4 - v.e2 * v.e3;
+      double E = v.e2 * (cp0[t] - cpb[t - 1]) - v.e4 * (cm0[t] - cmb[t - 1]);
+      double r = rcp_nr(B - A * cp);
+      const double cn = D * r, dn = (E - A * dp) * r, ln = (-A * lp) * r;
+      rc[2 * t - 1] = cn; rd[2 * t - 1] = dn; rl[2 * t - 1] = ln;
+      // row 2t
+      A = u.e2 * u.e3 - u.e4 * u.e1; B = u.e1 * v.e1 - u.e3 * v.e3; D = u.e3 * v.e4 - u.e1 * v.e2;
+      E = u.e3 * (cp0[t] - cpb[t - 1]) + u.e1 * (cmb[t - 1] - cm0[t]);
+      r = rcp_nr(B - A * cn);
+      cp = D * r; dp = (E - A * dn) * r; lp = (-A * ln) * r;
+      rc[2 * t] = cp; rd[2 * t] = dp; rl[2 * t] = lp;
+      u = v;
+    }
+    {
+      // last row: surface row (:113-117) or "e1 y1 + e2 y2 - Uin = -cpb"
+      const double A = is_sfc ? u.e1 - Rsfc * u.e3 : u.e1;
+      const double B = is_sfc ? u.e2 - Rsfc * u.e4 : u.e2;
+      const double D = is_sfc ? 0.0 : -1.0;
+      const double E = is_sfc ? Ssfc - cpb[L - 1] + Rsfc * cmb[L - 1] : 0.0 - cpb[L - 1];
+      const double r = rcp_nr(B - A * cp);
+      rc[2 * L - 1] = D * r; rd[2 * L - 1] = (E - A * dp) * r; rl[2 * L - 1] = (-A * lp) * r;
+    }
+  }
+  // ---- upward: y_r = alpha_r + beta_r*Uin + gamma_r*Din   (alpha -> rd, beta -> rc, gamma -> rl)
+  {
+    double al = 0.0, be = 1.0, ga = 0.0;
+#pragma unroll
+    for (int r = 2 * L - 1; r >= 0; r--) {
+      const double cc = rc[r], dd = rd[r], lc = rl[r];
+      al = dd - cc * al; be = -cc * be; ga = -lc - cc * ga;
+      rd[r] = al; rc[r] = be; rl[r] = ga;
+    }
+  }
+  // ---- the chunk as an affine map of (Din, Uin): up-flux leaving through its top (fup(1) form,
+  //      :143), down-flux through its bottom (:147)
+  const E4 ea = make_e(G[0], X[0]), eb = make_e(G[L - 1], X[L - 1]);
+  double uS = rd[0] * ea.e3 - rd[1] * ea.e4 + cp0[0], uD = rl[0] * ea.e3 - rl[1] * ea.e4, uU = rc[0] * ea.e3 - rc[1] * ea.e4;
+  double dS = rd[2 * L - 2] * eb.e3 + rd[2 * L - 1] * eb.e4 + cmb[L - 1], dD = rl[2 * L - 2] * eb.e3 + rl[2 * L - 1] * eb.e4,
+         dU = rc[2 * L - 2] * eb.e3 + rc[2 * L - 1] * eb.e4;
+  // a chunk without any real layer (columns of fewer than 64 layers) is the identity exactly, not
+  // to the rounding of L zero-thickness layers: with up to 63 such chunks in a row that rounding --
+  // an ulp of the Planck source each -- would show in fluxes much smaller than the source
+  if (pad == L) { uS = 0.0; uD = 0.0; uU = 1.0; dS = 0.0; dD = 1.0; dU = 0.0; }
+  TSTAMP(3);
+  // ---- bottom-up suffix scan of the projective reflectance recursion
+  M7 P;
+  P.m00 = uU * dD - uD * dU; P.m02 = uD; P.m10 = uU * dS - uS * dU; P.m11 = uU; P.m12 = uS; P.m20 = -dU; P.m22 = 1.0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const M7 R = m7_shfl_down(P, d);
+    if (lane + d < 64) P = m7_mul(P, R);
+  }
+  TSTAMP(4);
+  // P applied to (0,0,1): state above chunk `lane`; the state below it lives one lane down
+  const double rinv = rcp_nr(P.m22);
+  const double rho_above = P.m02 * rinv, sig_above = P.m12 * rinv;
+  double rho = __shfl_down(rho_above, 1), sig = __shfl_down(sig_above, 1);
+  if (lane == 63) { rho = 0.0; sig = 0.0; }
+  // ---- top-down affine scan: Din_{q+1} = alpha_q + beta_q*Din_q
+  const double mm = rcp_nr(1.0 - rho * dU);
+  double sa = dS + dU * mm * (rho * dS + sig);
+  double sb = dD * (1.0 + dU * mm * rho);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double pa = __shfl_up(sa, d), pb = __shfl_up(sb, d);
+    if (lane >= d) { sa = sa + sb * pa; sb = sb * pb; }
+  }
+  double Din = __shfl_up(sa, 1);
+  if (lane == 0) Din = 0.0;
+  const double Uin = mm * (rho * dS + sig + rho * dD * Din);
+  TSTAMP(5);
+
+  // ---- level fluxes (:143-148, :288-293), mean intensity (:135-140), g-point weight
+  double *sFu = lds + (size_t)(0 * TSW_COLS + wave) * nl;
+  double *sFd = lds + (size_t)(1 * TSW_COLS + wave) * nl;
+  double *sAm = lds + (size_t)(2 * TSW_COLS + wave) * nl;
+#pragma unroll
+  for (int t = 0; t < L; t++) {
+    const int i = a + t - pad;
+    const E4 e = make_e(G[t], X[t]);
+    const double y1 = rd[2 * t] + rc[2 * t] * Uin + rl[2 * t] * Din;
+    const double y2 = rd[2 * t + 1] + rc[2 * t + 1] * Uin + rl[2 * t + 1] * Din;
+    if (t >= pad) {
+      sFu[i + 1] = wcol * (y1 * e.e1 + y2 * e.e2 + cpb[t]);
+      sFd[i + 1] = wcol * ((y1 * e.e3 + y2 * e.e4 + cmb[t]) + dir[t]);
+      sAm[i + 1] = wcol * (inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + cpb[t] + cmb[t]) + diru[t]);
+      if (i == 0) {
+        const double top = (y1 * e.e3 - y2 * e.e4) + cp0[t];
+        sFu[0] = wcol * top;
+        sFd[0] = wcol * lvl0_dn;
+        sAm[0] = wcol * (inv_u1 * top + lvl0_am);
+      }
+    }
+  }
+  TSTAMP(6);
+  __syncthreads();
+  TSTAMP(7);
+  // ---- sum over the block's g-points, unit factors (radiate.f90:167-180), reversal (:140-154)
+  const bool split = p.accumulate != 0;
+  double scale = 1.0;
+  if (solar) scale = p.photons_sol[ll] * p.photon_scale_factor;  // clima_radtran.f90:302
+  for (int n = threadIdx.x; n < nl; n += blockDim.x) {
+    double fu = 0.0, fd = 0.0, am = 0.0;
+#pragma unroll
+    for (int w = 0; w < TSW_COLS; w++) {
+      fu = fu + lds[(size_t)(0 * TSW_COLS + w) * nl + n];
+      fd = fd + lds[(size_t)(1 * TSW_COLS + w) * nl + n];
+      am = am + lds[(size_t)(2 * TSW_COLS + w) * nl + n];
+    }
+    const size_t o = (size_t)ll * nl + (nz - n);
+    if (solar) {
+      fu = fu * scale * p.diurnal_fac;
+      fd = fd * scale * p.diurnal_fac;
+      am = am * scale * p.diurnal_fac;
+      am = am * p.am_f1[ll];
+      am = am * p.am_f2[ll] * p.am_dw[ll];
+      if (split) { atomicAdd(&p.sol_fup_a[o], fu); atomicAdd(&p.sol_fdn_a[o], fd); atomicAdd(&p.sol_amean[o], am); }
+      else { p.sol_fup_a[o] = fu; p.sol_fdn_a[o] = fd; p.sol_amean[o] = am; }
+    } else {
+      const size_t ob = o + (size_t)bz * p.b_out;
+      if (split) { atomicAdd(&p.ir_fup_a[ob], fu); atomicAdd(&p.ir_fdn_a[ob], fd); }
+      else { p.ir_fup_a[ob] = fu; p.ir_fdn_a[ob] = fd; }
+    }
+  }
+  if (gy == 0 && p.col_base == 0 && p.b_out == 0) {
+    double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
+    for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = ld_opr<COHERENT>(&p.tau_band[(size_t)l * nz + (nz - 1 - i)]);
+  }
+  TSTAMP(8);
+#undef TSTAMP
+}
+
 // one launch for both channels: blocks [0, n_sol) are solar bins (the heavier ones first),
 // blocks [n_sol, n_sol+n_ir) IR bins
 // LMAX = 8 would take 260 VGPRs (one wave per SIMD); capping it at 256 costs a few spills and buys
@@ -1798,8 +2160,13 @@ __device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const
 template <int LMAX>
 __global__ __launch_bounds__(64 * TSW_COLS, LMAX > 4 ? 2 : 1) void k_twostream_w(TwoStreamParams p) {
   extern __shared__ __align__(16) double lds[];  // [3][TSW_COLS][nz+1] weighted level values
-  if ((int)blockIdx.x < p.n_sol) twostream_w_body<LMAX, true, false, 0>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
-  else twostream_w_body<LMAX, false, false, 0>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
+  if constexpr (LMAX <= 4) {  // the straight-line form, as in k_fused: the two launch forms give the same bits
+    if ((int)blockIdx.x < p.n_sol) twostream_p_body<LMAX, true, 0, false, false>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
+    else twostream_p_body<LMAX, false, 0, false, false>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
+  } else {
+    if ((int)blockIdx.x < p.n_sol) twostream_w_body<LMAX, true, false, 0>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
+    else twostream_w_body<LMAX, false, false, 0>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
+  }
 }
 
 static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
@@ -2329,8 +2696,8 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
 #else
   const int tslot = -1;
 #endif
-  if (solar) twostream_w_body<4, true, true, FUSED_NZMAX>(ts, bl, lds, gy, 0, tslot);
-  else twostream_w_body<4, false, true, 0>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
+  if (solar) twostream_p_body<4, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot);
+  else twostream_p_body<4, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
 #ifdef CLIMA_STAMPS
   __syncthreads();
   if (op.stamps && threadIdx.x == 0) op.stamps[64 + 2 * 3128 + 3 * b + 2] = __builtin_amdgcn_s_memrealtime();

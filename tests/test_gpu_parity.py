@@ -3,8 +3,8 @@ inputs.  Floating-point path: tolerances are stated here.
 
 north_star tolerance: OLR within 1e-4 relative of the reference.  What is enforced:
   * OLR / ISR ............................ 1e-9 relative
-  * level fluxes fup_n, fdn_n, f_total .... 1e-9 of the profile maximum
-  * per-bin spectra fup_a, fdn_a, amean ... 1e-8 of the array maximum
+  * level fluxes fup_n, fdn_n, f_total .... 1e-9 of the channel's profile maximum (up and down together)
+  * per-bin spectra fup_a, fdn_a, amean ... 1e-8 of the array maximum (fup_a, fdn_a together)
   * opr tau, w0, g, tau_band .............. 1e-11 relative (k-table exp() argument rounding
     bounds this at ~3e-14; measured 2.8e-14)
 Differences come from device exp/log10 (<=1 ulp), FMA contraction, reciprocal-multiply in
@@ -51,10 +51,17 @@ def _compare(r, o, col, flux_tol_scale=1.0, **kw):
     assert abs(olr - olr_o) <= f * RTOL_TOA * abs(olr_o)
     assert abs(isr - isr_o) <= f * RTOL_TOA * max(abs(isr_o), 1e-300)
     for wg, wo in ((r.wrk_ir, o.wrk_ir), (r.wrk_sol, o.wrk_sol)):
-        assert _scaled(wg.fup_n, wo.fup_n) <= f * TOL_LEVEL
-        assert _scaled(wg.fdn_n, wo.fdn_n) <= f * TOL_LEVEL
-        assert _scaled(wg.fup_a, wo.fup_a) <= f * TOL_SPEC
-        assert _scaled(wg.fdn_a, wo.fdn_a) <= f * TOL_SPEC
+        # The up and down fluxes of a channel come out of one linear solve as sums of terms of the
+        # size of the larger of the two (y1*e + y2*e + C, twostream.f90:143-148): where one of them
+        # is orders of magnitude below the other (a single optically thin layer: fdn 7.5 against
+        # fup 3e8 in fuzz case 51) an ulp of the large terms is 1e-8 of the small flux -- in the
+        # reference's own arithmetic just as here.  So both are measured on their common scale.
+        n_scale = max(float(np.max(np.abs(wo.fup_n))), float(np.max(np.abs(wo.fdn_n))), 1e-300)
+        a_scale = max(float(np.max(np.abs(wo.fup_a))), float(np.max(np.abs(wo.fdn_a))), 1e-300)
+        assert float(np.max(np.abs(np.asarray(wg.fup_n) - np.asarray(wo.fup_n)))) <= f * TOL_LEVEL * n_scale
+        assert float(np.max(np.abs(np.asarray(wg.fdn_n) - np.asarray(wo.fdn_n)))) <= f * TOL_LEVEL * n_scale
+        assert float(np.max(np.abs(np.asarray(wg.fup_a) - np.asarray(wo.fup_a)))) <= f * TOL_SPEC * a_scale
+        assert float(np.max(np.abs(np.asarray(wg.fdn_a) - np.asarray(wo.fdn_a)))) <= f * TOL_SPEC * a_scale
         assert _scaled(wg.amean, wo.amean) <= f * TOL_SPEC
         assert _rel(wg.tau_band, wo.tau_band) <= RTOL_OPR
     assert _scaled(r.f_total, o.f_total) <= f * TOL_LEVEL
