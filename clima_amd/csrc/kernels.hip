@@ -1957,13 +1957,16 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     // batched shared-opacity IR launches: blockIdx.z selects the temperature column (strides 0 otherwise)
     const double *Tcol = p.T + (size_t)bz * p.b_T;
     const double *Tsfc = p.T_surface + (size_t)bz * p.b_Ts;
-    // Planck at the L+1 faces of the slots (level a for every face of a zero-thickness slot)
+    // Planck source at the levels (radiate.f90:65-69): the same for the block's g-point columns, so
+    // each of the nz+1 values is computed once per block instead of L+1 times per lane of every wave
+    double *sB = lds + (size_t)3 * TSW_COLS * nl;
+    for (int n = threadIdx.x; n < nl; n += blockDim.x)  // TOA-first level
+      sB[n] = planck(avg_freq, n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);
+    __syncthreads();
+    // the L+1 faces of the slots (level a for every face of a zero-thickness slot)
     double bpl[L + 1];
 #pragma unroll
-    for (int s = 0; s <= L; s++) {
-      const int n = a + max(s - pad, 0);  // TOA-first level
-      bpl[s] = planck(avg_freq, n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);  // radiate.f90:65-69
-    }
+    for (int s = 0; s <= L; s++) bpl[s] = sB[a + max(s - pad, 0)];
     TSTAMP(1);
 #pragma unroll
     for (int t = 0; t < L; t++) {
@@ -2193,7 +2196,7 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   const int lmax = (p.nz + 63) / 64;
   if (lmax > 8) return false;
   const int groups = (p.ng + TSW_COLS - 1) / TSW_COLS;
-  const size_t lds = sizeof(double) * 3 * TSW_COLS * ((size_t)p.nz + 1);
+  const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)p.nz + 1);  // level values of the columns + the bin's Planck table
   if (lds_bytes) *lds_bytes = lds;
   if (lds > 160 * 1024) return false;
   const int grid = p.n_sol + p.n_ir;
@@ -2718,7 +2721,7 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
   fp.n_op = (int)((total + OP_THREADS - 1) / OP_THREADS);
   const int groups = (ts.ng + TSW_COLS - 1) / TSW_COLS;  // 2
   ts.col_base = 0; ts.accumulate = 1;
-  const size_t lds = sizeof(double) * 3 * TSW_COLS * ((size_t)ts.nz + 1);
+  const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)ts.nz + 1);
   const dim3 grid(fp.n_op + nb * groups), blk(OP_THREADS);
   if (op.cust.on) {
     if (op.multi_edge) hipLaunchKernelGGL((k_fused<true, true>), grid, blk, lds, s, op, ts, fp);
