@@ -1427,10 +1427,10 @@ void clima_test_device_rcp(const int *n, const double *x, double *y, char *err) 
   clear_err(err);
   TRY
   DevBuf<double> dx, dy;
-  dx.alloc(*n); dy.alloc((size_t)3 * *n);
+  dx.alloc(*n); dy.alloc((size_t)4 * *n);
   HIPCHK(hipMemcpy(dx.p, x, sizeof(double) * *n, hipMemcpyHostToDevice));
   launch_test_rcp(dx.p, dy.p, *n, nullptr);
-  HIPCHK(hipMemcpy(y, dy.p, sizeof(double) * 3 * *n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(y, dy.p, sizeof(double) * 4 * *n, hipMemcpyDeviceToHost));
   CATCH(err)
 }
 

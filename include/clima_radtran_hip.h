@@ -185,7 +185,8 @@ void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double 
 
 /* test hook: y[i] = the kernels' device exp(x[i]) (used where the reference calls exp) */
 void clima_test_device_exp(const int *n, const double *x, double *y, char *err);
-/* test hook: the device reciprocal with 0, 1 and 2 Newton steps (y: 3 arrays of n) */
+/* test hook: the device reciprocal with 0, 1 and 2 Newton steps, and the device sqrt of |x|
+ * (y: 4 arrays of n) */
 void clima_test_device_rcp(const int *n, const double *x, double *y, char *err);
 /* test hook: the DPP wave scans of the kernels on nwaves*64 values (out: 4 arrays of that length:
  * affine inclusive scan, the same through build+apply, shift up by one lane, lane reversal) */

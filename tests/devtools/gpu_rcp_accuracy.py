@@ -4,9 +4,9 @@ from clima_amd import lib
 L = lib.load()
 rng = np.random.default_rng(0)
 x = np.concatenate([10.0 ** rng.uniform(-300, 300, 200000), rng.uniform(1.0, 2.0, 200000), -10.0 ** rng.uniform(-5, 5, 1000)])
-y = np.empty(3 * len(x)); err = C.create_string_buffer(1025); dp = C.POINTER(C.c_double)
+y = np.empty(4 * len(x)); err = C.create_string_buffer(1025); dp = C.POINTER(C.c_double)
 L.clima_test_device_rcp(C.byref(C.c_int(len(x))), x.ctypes.data_as(dp), y.ctypes.data_as(dp), err)
-y = y.reshape(3, -1)
+y = y.reshape(4, -1)
 ref = 1.0 / x
 for k in range(3):
     rel = np.abs(y[k] - ref) / np.abs(ref)

@@ -99,6 +99,23 @@ def test_device_exp(hip_lib):
     assert np.all(np.abs(y[~normal & (ref > 0) & np.isfinite(ref)] - ref[~normal & (ref > 0) & np.isfinite(ref)]) <= 1e-300)
 
 
+def test_device_rcp_and_sqrt(hip_lib):
+    """The kernels' reciprocal (v_rcp_f64 + 2 Newton steps) and square root (v_rsq_f64 + Goldschmidt),
+    used where the reference divides or calls sqrt on quantities of ordinary size: <= 1 ulp."""
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    x = np.concatenate([10.0 ** rng.uniform(-6, 6, 200000), rng.uniform(1.0, 4.0, 200000)])
+    y = np.empty(4 * len(x))
+    err = C.create_string_buffer(1025)
+    dp = C.POINTER(C.c_double)
+    hip_lib.clima_test_device_rcp(C.byref(C.c_int(len(x))), x.ctypes.data_as(dp), y.ctypes.data_as(dp), err)
+    assert err.value == b""
+    y = y.reshape(4, -1)
+    for got, ref in ((y[2], 1.0 / x), (y[3], np.sqrt(x))):
+        ulp = np.abs(got - ref) / np.spacing(ref)
+        assert ulp.max() <= 1.0, ulp.max()
+
+
 def test_dpp_wave_scans(hip_lib):
     # the DPP-based affine wave scan used by the batched IR kernel, against a serial recurrence
     import ctypes as C
