@@ -1438,6 +1438,84 @@ bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
 // A block is 4 waves = 4 g-point columns of one bin; their weighted level fluxes meet in LDS
 // once at the end.
 // ------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------
+// Wave-wide affine scans over DPP (data-parallel primitives) instead of ds_bpermute shuffles.
+// x_i = a_i + b_i * x_{i-1} over the 64 lanes, as composition of the maps (a_i, b_i); the
+// schedule is the row_shr 1,2,3 / 4 / 8 / row_bcast 15 / row_bcast 31 sequence (7 steps, each a
+// DPP move of the two halves of a double: a few cycles, where a ds_bpermute round trip is ~100).
+// A lane with no source in a step keeps `old`: 0 for an a-part, 1 for a b-part, which makes the
+// step the identity for it -- no participation masks needed.
+// ------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov(double old, double src) {
+  const long long o = __double_as_longlong(old), v = __double_as_longlong(src);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(v >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+constexpr int WSCAN_STEPS = 7;
+
+// value a step brings in from the lower lane(s); `orig` is the value before the scan (steps 0-2
+// read the original neighbours), `cur` the running one
+template <int STEP>
+__device__ __forceinline__ double wscan_fetch(double old, double orig, double cur) {
+  if constexpr (STEP == 0) return dpp_mov<DPP_ROW_SHR + 1, 0xf, 0xf>(old, orig);
+  else if constexpr (STEP == 1) return dpp_mov<DPP_ROW_SHR + 2, 0xf, 0xf>(old, orig);
+  else if constexpr (STEP == 2) return dpp_mov<DPP_ROW_SHR + 3, 0xf, 0xf>(old, orig);
+  else if constexpr (STEP == 3) return dpp_mov<DPP_ROW_SHR + 4, 0xf, 0xe>(old, cur);
+  else if constexpr (STEP == 4) return dpp_mov<DPP_ROW_SHR + 8, 0xf, 0xc>(old, cur);
+  else if constexpr (STEP == 5) return dpp_mov<DPP_ROW_BCAST15, 0xa, 0xf>(old, cur);
+  else return dpp_mov<DPP_ROW_BCAST31, 0xc, 0xf>(old, cur);
+}
+
+// Full scan of (a, b); bstep[k] receives the multiplier lane i applies in step k, so that later
+// scans with the same b's but other a's only need wscan_apply.
+template <int STEP>
+__device__ __forceinline__ void wscan_build_step(double &a, double &b, const double a0, const double b0, double *bstep) {
+  const double ta = wscan_fetch<STEP>(0.0, a0, a);
+  const double tb = wscan_fetch<STEP>(1.0, b0, b);
+  bstep[STEP] = b;
+  a = a + b * ta;
+  b = b * tb;
+}
+__device__ __forceinline__ void wscan_build(double &a, double &b, double *bstep) {
+  const double a0 = a, b0 = b;
+  wscan_build_step<0>(a, b, a0, b0, bstep); wscan_build_step<1>(a, b, a0, b0, bstep);
+  wscan_build_step<2>(a, b, a0, b0, bstep); wscan_build_step<3>(a, b, a0, b0, bstep);
+  wscan_build_step<4>(a, b, a0, b0, bstep); wscan_build_step<5>(a, b, a0, b0, bstep);
+  wscan_build_step<6>(a, b, a0, b0, bstep);
+}
+// a-part only, with the multipliers of a previous wscan_build (read through `bs(k)`)
+template <class BS>
+__device__ __forceinline__ double wscan_apply(double a, BS bs) {
+  const double a0 = a;
+  a = a + bs(0) * wscan_fetch<0>(0.0, a0, a);
+  a = a + bs(1) * wscan_fetch<1>(0.0, a0, a);
+  a = a + bs(2) * wscan_fetch<2>(0.0, a0, a);
+  a = a + bs(3) * wscan_fetch<3>(0.0, a0, a);
+  a = a + bs(4) * wscan_fetch<4>(0.0, a0, a);
+  a = a + bs(5) * wscan_fetch<5>(0.0, a0, a);
+  a = a + bs(6) * wscan_fetch<6>(0.0, a0, a);
+  return a;
+}
+// inclusive prefix sum over the 64 lanes (same schedule, a-part only with unit multipliers)
+__device__ __forceinline__ double wscan_sum(double a) {
+  const double a0 = a;
+  a = a + wscan_fetch<0>(0.0, a0, a);
+  a = a + wscan_fetch<1>(0.0, a0, a);
+  a = a + wscan_fetch<2>(0.0, a0, a);
+  a = a + wscan_fetch<3>(0.0, a0, a);
+  a = a + wscan_fetch<4>(0.0, a0, a);
+  a = a + wscan_fetch<5>(0.0, a0, a);
+  a = a + wscan_fetch<6>(0.0, a0, a);
+  return a;
+}
+// x[lane-1], 0 in lane 0
+__device__ __forceinline__ double wave_shr1(double x) { return dpp_mov<DPP_WAVE_SHR1, 0xf, 0xf>(0.0, x); }
+// x[63-lane]
+__device__ __forceinline__ double wave_reverse(double x) { return __shfl(x, 63 - (int)(threadIdx.x & 63)); }
+
 struct M7 {
   double m00, m02, m10, m11, m12, m20, m22;
 };
@@ -1902,14 +1980,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       tot = tot + taup[t];
     }
     // optical depth above the chunk (tauc, :64-67): exclusive wave scan of the chunk totals
-    double incl = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const double nb = __shfl_up(incl, d);
-      if (lane >= d) incl = incl + nb;
-    }
-    double tcum = __shfl_up(incl, 1);
-    if (lane == 0) tcum = 0.0;
+    double tcum = wave_shr1(wscan_sum(tot));  // DPP scans: no LDS round trips (0 enters lane 0)
     double tauc[L];
 #pragma unroll
     for (int t = 0; t < L; t++) {
@@ -2105,13 +2176,11 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   const double mm = rcp_nr(1.0 - rho * dU);
   double sa = dS + dU * mm * (rho * dS + sig);
   double sb = dD * (1.0 + dU * mm * rho);
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double pa = __shfl_up(sa, d), pb = __shfl_up(sb, d);
-    if (lane >= d) { sa = sa + sb * pa; sb = sb * pb; }
+  {
+    double bstep[WSCAN_STEPS];
+    wscan_build(sa, sb, bstep);
   }
-  double Din = __shfl_up(sa, 1);
-  if (lane == 0) Din = 0.0;
+  const double Din = wave_shr1(sa);
   const double Uin = mm * (rho * dS + sig + rho * dD * Din);
   TSTAMP(5);
 
@@ -2244,72 +2313,6 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
 
 
 
-
-// ------------------------------------------------------------------------------------
-// Wave-wide affine scans over DPP (data-parallel primitives) instead of ds_bpermute shuffles.
-// x_i = a_i + b_i * x_{i-1} over the 64 lanes, as composition of the maps (a_i, b_i); the
-// schedule is the row_shr 1,2,3 / 4 / 8 / row_bcast 15 / row_bcast 31 sequence (7 steps, each a
-// DPP move of the two halves of a double: a few cycles, where a ds_bpermute round trip is ~100).
-// A lane with no source in a step keeps `old`: 0 for an a-part, 1 for a b-part, which makes the
-// step the identity for it -- no participation masks needed.
-// ------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ double dpp_mov(double old, double src) {
-  const long long o = __double_as_longlong(old), v = __double_as_longlong(src);
-  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
-  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(v >> 32), CTRL, ROW_MASK, BANK_MASK, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
-constexpr int WSCAN_STEPS = 7;
-
-// value a step brings in from the lower lane(s); `orig` is the value before the scan (steps 0-2
-// read the original neighbours), `cur` the running one
-template <int STEP>
-__device__ __forceinline__ double wscan_fetch(double old, double orig, double cur) {
-  if constexpr (STEP == 0) return dpp_mov<DPP_ROW_SHR + 1, 0xf, 0xf>(old, orig);
-  else if constexpr (STEP == 1) return dpp_mov<DPP_ROW_SHR + 2, 0xf, 0xf>(old, orig);
-  else if constexpr (STEP == 2) return dpp_mov<DPP_ROW_SHR + 3, 0xf, 0xf>(old, orig);
-  else if constexpr (STEP == 3) return dpp_mov<DPP_ROW_SHR + 4, 0xf, 0xe>(old, cur);
-  else if constexpr (STEP == 4) return dpp_mov<DPP_ROW_SHR + 8, 0xf, 0xc>(old, cur);
-  else if constexpr (STEP == 5) return dpp_mov<DPP_ROW_BCAST15, 0xa, 0xf>(old, cur);
-  else return dpp_mov<DPP_ROW_BCAST31, 0xc, 0xf>(old, cur);
-}
-
-// Full scan of (a, b); bstep[k] receives the multiplier lane i applies in step k, so that later
-// scans with the same b's but other a's only need wscan_apply.
-template <int STEP>
-__device__ __forceinline__ void wscan_build_step(double &a, double &b, const double a0, const double b0, double *bstep) {
-  const double ta = wscan_fetch<STEP>(0.0, a0, a);
-  const double tb = wscan_fetch<STEP>(1.0, b0, b);
-  bstep[STEP] = b;
-  a = a + b * ta;
-  b = b * tb;
-}
-__device__ __forceinline__ void wscan_build(double &a, double &b, double *bstep) {
-  const double a0 = a, b0 = b;
-  wscan_build_step<0>(a, b, a0, b0, bstep); wscan_build_step<1>(a, b, a0, b0, bstep);
-  wscan_build_step<2>(a, b, a0, b0, bstep); wscan_build_step<3>(a, b, a0, b0, bstep);
-  wscan_build_step<4>(a, b, a0, b0, bstep); wscan_build_step<5>(a, b, a0, b0, bstep);
-  wscan_build_step<6>(a, b, a0, b0, bstep);
-}
-// a-part only, with the multipliers of a previous wscan_build (read through `bs(k)`)
-template <class BS>
-__device__ __forceinline__ double wscan_apply(double a, BS bs) {
-  const double a0 = a;
-  a = a + bs(0) * wscan_fetch<0>(0.0, a0, a);
-  a = a + bs(1) * wscan_fetch<1>(0.0, a0, a);
-  a = a + bs(2) * wscan_fetch<2>(0.0, a0, a);
-  a = a + bs(3) * wscan_fetch<3>(0.0, a0, a);
-  a = a + bs(4) * wscan_fetch<4>(0.0, a0, a);
-  a = a + bs(5) * wscan_fetch<5>(0.0, a0, a);
-  a = a + bs(6) * wscan_fetch<6>(0.0, a0, a);
-  return a;
-}
-// x[lane-1], 0 in lane 0
-__device__ __forceinline__ double wave_shr1(double x) { return dpp_mov<DPP_WAVE_SHR1, 0xf, 0xf>(0.0, x); }
-// x[63-lane]
-__device__ __forceinline__ double wave_reverse(double x) { return __shfl(x, 63 - (int)(threadIdx.x & 63)); }
 
 __global__ void k_test_wscan(const double *a, const double *b, double *out, int nwaves) {
   // out[0]: inclusive affine scan x_i = a_i + b_i x_{i-1}; out[1]: the same through build + apply;
