@@ -1538,6 +1538,23 @@ __device__ __forceinline__ M7 m7_shfl_down(const M7 &a, int d) {
   return r;
 }
 
+// One step of the DPP prefix scan (wscan_fetch schedule) of 3x3 products P_i <- P_i * P_{i-1} * ...:
+// a lane without a source in the step multiplies by the identity
+template <int STEP>
+__device__ __forceinline__ void m7_scan_step(M7 &P, const M7 &P0) {
+  M7 R;
+  R.m00 = wscan_fetch<STEP>(1.0, P0.m00, P.m00); R.m02 = wscan_fetch<STEP>(0.0, P0.m02, P.m02);
+  R.m10 = wscan_fetch<STEP>(0.0, P0.m10, P.m10); R.m11 = wscan_fetch<STEP>(1.0, P0.m11, P.m11);
+  R.m12 = wscan_fetch<STEP>(0.0, P0.m12, P.m12); R.m20 = wscan_fetch<STEP>(0.0, P0.m20, P.m20);
+  R.m22 = wscan_fetch<STEP>(1.0, P0.m22, P.m22);
+  P = m7_mul(P, R);
+}
+__device__ __forceinline__ void m7_prefix_scan(M7 &P) {
+  const M7 P0 = P;
+  m7_scan_step<0>(P, P0); m7_scan_step<1>(P, P0); m7_scan_step<2>(P, P0); m7_scan_step<3>(P, P0);
+  m7_scan_step<4>(P, P0); m7_scan_step<5>(P, P0); m7_scan_step<6>(P, P0);
+}
+
 constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
 
 template <int LMAX, bool SOLAR, bool COHERENT, int NZMAX>
@@ -2158,20 +2175,18 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   // an ulp of the Planck source each -- would show in fluxes much smaller than the source
   if (pad == L) { uS = 0.0; uD = 0.0; uU = 1.0; dS = 0.0; dD = 1.0; dU = 0.0; }
   TSTAMP(3);
-  // ---- bottom-up suffix scan of the projective reflectance recursion
+  // ---- bottom-up suffix scan of the projective reflectance recursion: the chunk matrices are
+  //      mirrored across the wave (one LDS permute each), which turns it into a prefix scan that
+  //      runs over DPP -- 2 LDS round trips instead of 6, and no participation selects
   M7 P;
-  P.m00 = uU * dD - uD * dU; P.m02 = uD; P.m10 = uU * dS - uS * dU; P.m11 = uU; P.m12 = uS; P.m20 = -dU; P.m22 = 1.0;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const M7 R = m7_shfl_down(P, d);
-    if (lane + d < 64) P = m7_mul(P, R);
-  }
+  P.m00 = wave_reverse(uU * dD - uD * dU); P.m02 = wave_reverse(uD); P.m10 = wave_reverse(uU * dS - uS * dU);
+  P.m11 = wave_reverse(uU); P.m12 = wave_reverse(uS); P.m20 = wave_reverse(-dU); P.m22 = 1.0;
+  m7_prefix_scan(P);
   TSTAMP(4);
-  // P applied to (0,0,1): state above chunk `lane`; the state below it lives one lane down
+  // P applied to (0,0,1): the state above chunk 63-lane; the state below a chunk is that of the
+  // chunk under it, one (mirrored) lane down, and 0 under the last chunk
   const double rinv = rcp_nr(P.m22);
-  const double rho_above = P.m02 * rinv, sig_above = P.m12 * rinv;
-  double rho = __shfl_down(rho_above, 1), sig = __shfl_down(sig_above, 1);
-  if (lane == 63) { rho = 0.0; sig = 0.0; }
+  const double rho = wave_reverse(wave_shr1(P.m02 * rinv)), sig = wave_reverse(wave_shr1(P.m12 * rinv));
   // ---- top-down affine scan: Din_{q+1} = alpha_q + beta_q*Din_q
   const double mm = rcp_nr(1.0 - rho * dU);
   double sa = dS + dU * mm * (rho * dS + sig);
