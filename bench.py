@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 KERNELS = ["prep", "opacity", "twostream", "integrate"]
-EVENT_STRIDE = 8   # HIP events around the dominant kernel on every 8th launch of the timed region
+EVENT_STRIDE = 16  # HIP events around the dominant kernel on every 16th launch of the timed region (first one included)
 # HBM bytes of one k_opacity8 launch on this exact workload from the PMC passes committed under
 # profiles/ (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; bench.py cannot collect counters itself)
 PMC_TRAFFIC_BYTES = {"fused": (2.737e4 + 4.739e4) * 1024.0,      # profiles/r01h_pmc_summary.md, k_fused
@@ -42,8 +42,8 @@ PMC_TRAFFIC_SOURCE = "FETCH_SIZE + WRITE_SIZE (KiB) of the dominant kernel per l
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--nz", type=int, default=200)
     ap.add_argument("--nzen", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -123,9 +123,17 @@ def main():
         step()
     # HIP events bracket the dominant kernel on the library's stream during the timed region, on
     # every EVENT_STRIDE-th launch (an event pair drains the queue for ~5 us; sampled, the
-    # measurement costs the measured throughput ~0.5 us per step instead): the average of these
-    # durations is roofline.achieved's denominator.  The per-kernel breakdown comes from a short
-    # fully instrumented pass after the timed region.
+    # measurement costs the measured throughput ~0.3 us per step instead): the average of these
+    # durations is roofline.achieved's denominator.
+    # The short fully instrumented pass (per-kernel breakdown) runs first, so that the timed
+    # region is not also the one in which the device clocks settle.
+    rad.profile_stride(1)
+    rad.profile(True)
+    rad.profile_reset()
+    for _ in range(min(max(args.steps, 1), 50)):
+        step()
+    barrier()
+    kt = [rad.kernel_time(i) for i in range(4)]
     rad.profile(2)
     rad.profile_stride(EVENT_STRIDE)
     rad.profile_reset()
@@ -136,15 +144,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kt_dom = rad.kernel_time(1)
-    rad.profile_stride(1)
-    rad.profile(True)
-    rad.profile_reset()
-    for _ in range(min(args.steps, 50)):
-        step()
-    barrier()
-    kt = [rad.kernel_time(i) for i in range(4)]
-    if kt_dom[1] > 0:   # (fewer timed steps than the event stride: keep the breakdown pass's figure)
+    if kt_dom[1] > 0:
         kt[1] = kt_dom
+    rad.profile_stride(1)
     rad.profile(False)
 
     if dist_on:

@@ -1328,6 +1328,7 @@ void radtran_profile_reset(void *ptr) {
   Radtran *r = as_rad(ptr);
   if (!r) return;
   for (int i = 0; i < 4; i++) { r->k_ms[i] = 0; r->k_n[i] = 0; }
+  r->timer_calls = r->profile_stride - 1;  // with a sampling stride, the next call is a sampled one
 }
 void radtran_kernel_time_get(void *ptr, const int *kernel_id, double *ms_total, int *launches, char *err) {
   clear_err(err);
