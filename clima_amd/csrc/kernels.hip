@@ -2307,6 +2307,9 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   if (groups > 1 && !zeroed) ts_zero_outputs(p, s);
   static bool attr = false;
   if (!attr) {
+    (void)hipFuncSetAttribute((const void *)k_twostream_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_twostream_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_twostream_w<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_twostream_w<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_twostream_w<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
@@ -2320,7 +2323,10 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
     p.col_base = g0 * TSW_COLS;
     p.accumulate = groups > 1 ? 1 : 0;
     const dim3 g(grid, per_launch, p.b_ncol > 0 ? p.b_ncol : 1);
-    if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4>), g, blk, lds, s, p);
+    if (lmax <= 1) hipLaunchKernelGGL((k_twostream_w<1>), g, blk, lds, s, p);
+    else if (lmax <= 2) hipLaunchKernelGGL((k_twostream_w<2>), g, blk, lds, s, p);
+    else if (lmax <= 3) hipLaunchKernelGGL((k_twostream_w<3>), g, blk, lds, s, p);
+    else if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4>), g, blk, lds, s, p);
     else hipLaunchKernelGGL((k_twostream_w<8>), g, blk, lds, s, p);
   }
   return true;
@@ -2736,8 +2742,21 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
 #else
   const int tslot = -1;
 #endif
-  if (solar) twostream_p_body<4, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot);
-  else twostream_p_body<4, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
+  // The number of slots per lane follows the column height (65-128 layers: 2, up to 192: 3, up to
+  // 256: 4).  Columns of at most 64 layers are not fused at all (fused_supported): their opacity
+  // blocks do not fill the machine once, so there is no half-empty second round to fill, and the
+  // stand-alone one-slot two-stream kernel runs at five waves per SIMD instead of two.  (A fourth
+  // variant in this kernel made hipcc spill 800 bytes per lane: 190 us instead of 116.)
+  if (fp.slots == 2) {
+    if (solar) twostream_p_body<2, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot);
+    else twostream_p_body<2, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
+  } else if (fp.slots == 3) {
+    if (solar) twostream_p_body<3, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot);
+    else twostream_p_body<3, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
+  } else {
+    if (solar) twostream_p_body<4, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot);
+    else twostream_p_body<4, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
+  }
 #ifdef CLIMA_STAMPS
   __syncthreads();
   if (op.stamps && threadIdx.x == 0) op.stamps[64 + 2 * 3128 + 3 * b + 2] = __builtin_amdgcn_s_memrealtime();
@@ -2747,7 +2766,7 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
 // false when the configuration is outside what the fused form covers (the caller then uses the
 // separate launches)
 bool fused_supported(const OpacityParams &op, const TwoStreamParams &ts) {
-  if (op.ng != 8 || (ts.nz + 63) / 64 > 4 || ts.nzen > MAX_ZEN) return false;
+  if (op.ng != 8 || (ts.nz + 63) / 64 > 4 || (ts.nz + 63) / 64 < 2 || ts.nzen > MAX_ZEN) return false;
   return (long)op.nbins * op.nz > 0 && ts.n_sol + ts.n_ir > 0;
 }
 
@@ -2756,6 +2775,7 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
   const long total = (long)op.nbins * op.nz;
   const int nb = ts.n_sol + ts.n_ir;
   fp.n_op = (int)((total + OP_THREADS - 1) / OP_THREADS);
+  fp.slots = (ts.nz + 63) / 64;  // 2..4 (fused_supported)
   const int groups = (ts.ng + TSW_COLS - 1) / TSW_COLS;  // 2
   ts.col_base = 0; ts.accumulate = 1;
   const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)ts.nz + 1);

@@ -167,6 +167,7 @@ struct FusedParams {
   int max_spins;   // bound of a two-stream block's wait
   int *done;       // [n_op]
   int *err_flag;
+  int slots;       // layers per lane of the two-stream part: ceil(nz/64) = 2..4 (launcher)
 };
 
 struct IntegrateParams {

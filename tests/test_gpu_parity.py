@@ -331,11 +331,13 @@ def test_workgroup_per_bin_kernel_agrees(O, small_tables, monkeypatch):
     _compare(r, o, S.modern_earth_column(50))
 
 
-@pytest.mark.parametrize("nz,nw", [(50, 40), (200, 60), (13, 7)])
+@pytest.mark.parametrize("nz,nw", [(50, 40), (200, 60), (13, 7), (65, 20), (100, 30), (128, 12), (129, 12), (150, 20), (192, 9), (256, 10)])
 def test_fused_and_separate_launch_forms(O, nz, nw, monkeypatch):
     # default: opacity + two-stream blocks in one grid (k_fused, block-to-block hand-off inside the
     # launch); radtran_fused_set(0) / CLIMA_HIP_FUSED=0: one launch per kernel.  Same opacities bit
-    # for bit (same code), same fluxes to rounding, both within tolerance of the oracle.
+    # for bit (same code), same fluxes to rounding, both within tolerance of the oracle.  The fused
+    # grid is used for 65..256 layers, with 2, 3 or 4 layer slots per lane (each boundary is here);
+    # shorter columns always take the separate launches.
     from clima_amd import synthetic as S
     from clima_amd.radtran import Radtran
     tb = S.modern_earth_tables(nw=nw, seed=31)
