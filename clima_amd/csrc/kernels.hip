@@ -1424,16 +1424,16 @@ bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
 // ------------------------------------------------------------------------------------
 // k_twostream_w: wave-per-column form of the two-stream solve (no block barriers, no
 // serial phase).  One wave = one (channel, bin, g-point) column; lane q owns the chunk of
-// consecutive layers [q*nz/64, (q+1)*nz/64) (<= LMAX layers) entirely in registers.  The
+// consecutive layers [q*nz/64, (q+1)*nz/64) (<= LMAX = ceil(nz/64) layers) entirely in registers.  The
 // chunk is solved as a two-stream problem of its own with flux boundary conditions (same
 // construction as dd_solve above), which turns it into an affine map
 //     (Din, Uin) -> (Dout, Uout) = (dS + dD*Din + dU*Uin,  uS + uD*Din + uU*Uin).
-// The 64 chunks of the column are joined by two wave-level scans over shuffles:
+// The 64 chunks of the column are joined by two wave-level scans (over DPP, below):
 //   * bottom-up: the reflectance/source (rho, sigma) seen from above each interface,
 //       Uin_{q-1} = rho_{q-1}*Din_q + sigma_{q-1},
 //     is a Moebius recursion in rho; written projectively, (n_rho, n_sigma, den) <- M_q * (...)
 //     with M_q = [[uU*dD-uD*dU, 0, uD], [uU*dS-uS*dU, uU, uS], [-dU, 0, 1]], it becomes a
-//     suffix product of 3x3 matrices (7 structural non-zeros), i.e. a 6-step Kogge-Stone scan;
+//     suffix product of 3x3 matrices (7 structural non-zeros), i.e. a Kogge-Stone scan;
 //   * top-down: Din_{q+1} = alpha_q + beta_q*Din_q, an affine prefix scan.
 // A block is 4 waves = 4 g-point columns of one bin; their weighted level fluxes meet in LDS
 // once at the end.
@@ -1530,13 +1530,6 @@ __device__ __forceinline__ M7 m7_mul(const M7 &l, const M7 &r) {
   p.m22 = l.m20 * r.m02 + l.m22 * r.m22;
   return p;
 }
-__device__ __forceinline__ M7 m7_shfl_down(const M7 &a, int d) {
-  M7 r;
-  r.m00 = __shfl_down(a.m00, d); r.m02 = __shfl_down(a.m02, d); r.m10 = __shfl_down(a.m10, d);
-  r.m11 = __shfl_down(a.m11, d); r.m12 = __shfl_down(a.m12, d); r.m20 = __shfl_down(a.m20, d);
-  r.m22 = __shfl_down(a.m22, d);
-  return r;
-}
 
 // One step of the DPP prefix scan (wscan_fetch schedule) of 3x3 products P_i <- P_i * P_{i-1} * ...:
 // a lane without a source in the step multiplies by the identity
@@ -1557,371 +1550,18 @@ __device__ __forceinline__ void m7_prefix_scan(M7 &P) {
 
 constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
 
-template <int LMAX, bool SOLAR, bool COHERENT, int NZMAX>
-__device__ __forceinline__ void twostream_w_body(const TwoStreamParams &p, const int bin_local, double *lds,
-                                                 const int gy, const int bz, const int tslot = -1) {
-#ifdef CLIMA_STAMPS
-#define TSTAMP(k)                                                                                  \
-  do {                                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-    if (tslot >= 0 && g_stamp_buf && threadIdx.x == 0) g_stamp_buf[tslot + (k)] = __builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-  } while (0)
-#else
-#define TSTAMP(k) do { } while (0)
-#endif
-  TSTAMP(0);
-  // exp with its constants resident in VGPRs where the register budget is there anyway (the
-  // fused grid: 256 per wave); the stand-alone kernel keeps three waves per SIMD instead
-  ExpK K;
-  if constexpr (COHERENT) K.load();
-  auto fexp = [&](double x) {
-    if constexpr (COHERENT) return fast_exp(x, K);
-    else return fast_exp(x);
-  };
-  auto planck = [&](double nu, double T) {
-    if constexpr (COHERENT) return planck_fcn(nu, T, K);
-    else return planck_fcn(nu, T);
-  };
-  const int nz = p.nz, ng = p.ng, nl = nz + 1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr bool solar = SOLAR;
-  const int ll = (solar ? p.sol_lo : p.ir_lo) + bin_local;
-  const int l = (solar ? p.sol_start : p.ir_start) + ll;  // opacity bin (radiate.f90:57)
-  const int c_raw = p.col_base + gy * TSW_COLS + wave;
-  const bool col_on = c_raw < ng;
-  const int c = col_on ? c_raw : ng - 1;
-  const double wcol = col_on ? p.wbin[c] : 0.0;  // g-point weight (radiate.f90:122-126)
-  const double *tauL = p.tau + ((size_t)l * ng + c) * nz;
-  const double *w0L = p.w0 + ((size_t)l * ng + c) * nz;
-  const double *gL = p.g + (size_t)l * nz;
-  const int a = (lane * nz) >> 6, b = ((lane + 1) * nz) >> 6, len = b - a;  // layers [a,b), TOA-first
-
-  // kept per layer for the flux evaluation, and the rows of the chunk's tridiagonal system
-  double G[LMAX], X[LMAX], cpb[LMAX], cmb[LMAX], dir[LMAX], diru[LMAX];
-  double rc[2 * LMAX], rd[2 * LMAX], rl[2 * LMAX];
-  double Rsfc, lvl0_dn = 0.0, lvl0_am = 0.0, cp0_top = 0.0;
-  const double inv_u1 = solar ? 1.7320508075688772 : 0.0;  // 1/u1, u1 = 1/sqrt(3) (solar only)
-  const double sqrt3 = 1.7320508075688772;
-
-  // ---- solar: optical depth above the chunk (tauc, twostream.f90:64-67) = exclusive wave
-  //      scan of the chunk totals of the delta-scaled optical depths
-  double tcum = 0.0;
-  if constexpr (solar) {
-    double tot = 0.0;
-#pragma unroll
-    for (int t = 0; t < LMAX; t++)
-      if (t < len) {
-        const double tau_in = ld_opr<COHERENT>(&tauL[a + t]), w0_in = ld_opr<COHERENT>(&w0L[a + t]), gt_in = ld_opr<COHERENT>(&gL[a + t]);
-        tot = tot + tau_in * (1.0 - w0_in * gt_in * gt_in);
-      }
-    double incl = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const double nb = __shfl_up(incl, d);
-      if (lane >= d) incl = incl + nb;
-    }
-    tcum = __shfl_up(incl, 1);
-    if (lane == 0) tcum = 0.0;
-    double wsum = 0.0, dir0 = 0.0;
-    for (int z = 0; z < p.nzen; z++) { wsum = wsum + p.zen_w_v[z]; dir0 = dir0 + p.zen_w_v[z] * p.zen_u_v[z]; }
-    lvl0_dn = dir0;   // direct(1) = u0 (:73)
-    lvl0_am = wsum;   // direct(1)/u0 = 1
-    Rsfc = p.albedo[ll];
-  } else {
-    Rsfc = p.has_hard_surface ? 1.0 - p.emissivity[ll] : 0.0;  // :186-190
-  }
-  TSTAMP(1);
-  const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64 (IR)
-  // batched shared-opacity IR launches: blockIdx.z selects the temperature column (strides 0 otherwise)
-  const double *Tcol = p.T + (size_t)bz * p.b_T;
-  const double *Tsfc = p.T_surface + (size_t)bz * p.b_Ts;
-
-  // ---- layer by layer: optical coefficients and source terms of layer t, then the rows of
-  //      the chunk's system that become complete with it, eliminated downward at once
-  //      (y_r + c' y_{r+1} + l*Din = d').  Row 2t-1 couples layers t-1,t (Fortran even rows,
-  //      :106-112), row 2t likewise (odd rows, :97-103); row 0 and the chunk's last row are
-  //      the flux boundary rows (TOA :93-96 / surface :113-117 at the column ends).
-  {
-    double cp = 0.0, dp = 0.0, lp = -1.0;
-    E4 u = make_e(0.0, 0.0);
-    double cpb_u = 0.0, cmb_u = 0.0;
-    double bpl_top = 0.0;  // IR: Planck at the top level of the current layer
-    // NZMAX: zenith angles whose direct-beam transmission exp(-tauc/u0) is carried from layer to
-    // layer inside the lane's chunk instead of recomputed (costs 2*NZMAX VGPRs: worth it only where
-    // the register budget is there anyway, i.e. in k_fused)
-    double etc[NZMAX + 1];
-#pragma unroll
-    for (int z = 0; z < NZMAX; z++) etc[z] = 1.0;
-    if constexpr (!solar)
-      if (len > 0) bpl_top = planck(avg_freq, a == nz ? *Tsfc : Tcol[nz - 1 - a]);
-#pragma unroll
-    for (int t = 0; t < LMAX; t++) {
-      G[t] = X[t] = cpb[t] = cmb[t] = dir[t] = diru[t] = 0.0;
-      rc[2 * t] = rc[2 * t + 1] = rd[2 * t] = rd[2 * t + 1] = rl[2 * t] = rl[2 * t + 1] = 0.0;
-      if (t < len) {
-        const int i = a + t;
-        const double tau_in = ld_opr<COHERENT>(&tauL[i]), w0_in = ld_opr<COHERENT>(&w0L[i]), gt_in = ld_opr<COHERENT>(&gL[i]);
-        double cp0, cm0, Ssfc = 0.0;
-        if constexpr (solar) {
-          // delta-Eddington (:38-40), quadrature coefficients (:43-44), lambda, Gamma (:50-51)
-          const double taup = tau_in * (1.0 - w0_in * gt_in * gt_in);
-          const double w0p = w0_in * (1.0 - gt_in * gt_in) / (1.0 - w0_in * gt_in * gt_in);
-          const double gtp = gt_in / (1.0 + gt_in);
-          const double gam1 = sqrt3 * (2.0 - w0p * (1 + gtp)) / 2.0;
-          const double gam2 = sqrt3 * w0p * (1.0 - gtp) / 2.0;
-          const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
-          G[t] = gam2 / (gam1 + lam);
-          X[t] = fexp(-lam * taup);  // :56
-          const double tauc = tcum;
-          tcum = tcum + taup;
-          // C+/C- and direct beam (:73-87) summed over the zenith angles with their weights
-          // (the matrix does not depend on u0: sum_z w_z*solve(E_z) == solve(sum_z w_z*E_z))
-          const double lam2 = lam * lam;
-          double CP0 = 0.0, CPB = 0.0, CM0 = 0.0, CMB = 0.0, DIR = 0.0, DIRU = 0.0;
-          auto zen = [&](const int z) {
-            const double u0 = p.zen_u_v[z], wz = p.zen_w_v[z], iu = p.zen_iu_v[z];
-            const double gam3 = (1.0 - sqrt3 * gtp * u0) / 2.0;
-            const double gam4 = 1.0 - gam3;
-            const double facp = w0p * ((gam1 - iu) * gam3 + gam4 * gam2);
-            const double facm = w0p * ((gam1 + iu) * gam4 + gam2 * gam3);
-            // exp(-tauc/u0) at the top of the layer (:78): computed for the chunk's first
-            // layer, afterwards carried from the layer above (etb there is the same quantity)
-            const double et0 = (t == 0) ? fexp(-tauc * iu) : etc[z];
-            const double etb = et0 * fexp(-taup * iu);  // :79
-            etc[z] = etb;
-            const double rden = wz * rcp_nr(lam2 - iu * iu);  // w_z / denom (:80)
-            const double fp = facp * rden, fm = facm * rden;
-            CP0 = __builtin_fma(et0, fp, CP0);
-            CPB = __builtin_fma(etb, fp, CPB);
-            CM0 = __builtin_fma(et0, fm, CM0);
-            CMB = __builtin_fma(etb, fm, CMB);
-            DIR = __builtin_fma(wz * u0, etb, DIR);   // direct(i+1) = u0*etb (:82)
-            DIRU = __builtin_fma(wz, etb, DIRU);      // direct(i+1)/u0
-          };
-          // all NZMAX carried angles present (the usual case): one straight-line block, so their
-          // constant loads batch and their chains interleave; otherwise angle by angle
-          if (NZMAX > 0 && p.nzen >= NZMAX) {
-#pragma unroll
-            for (int z = 0; z < NZMAX; z++) zen(z);
-          } else {
-#pragma unroll
-            for (int z = 0; z < NZMAX; z++)
-              if (z < p.nzen) zen(z);
-          }
-          for (int z = NZMAX; z < p.nzen; z++) {  // more zenith angles than the carried set: recompute
-            const double u0 = p.zen_u_v[z], wz = p.zen_w_v[z], iu = p.zen_iu_v[z];
-            const double gam3 = (1.0 - sqrt3 * gtp * u0) / 2.0;
-            const double gam4 = 1.0 - gam3;
-            const double facp = w0p * ((gam1 - iu) * gam3 + gam4 * gam2);
-            const double facm = w0p * ((gam1 + iu) * gam4 + gam2 * gam3);
-            const double et0 = fexp(-tauc * iu);
-            const double etb = et0 * fexp(-taup * iu);
-            const double rden = wz * rcp_nr(lam2 - iu * iu);
-            const double fp = facp * rden, fm = facm * rden;
-            CP0 = __builtin_fma(et0, fp, CP0);
-            CPB = __builtin_fma(etb, fp, CPB);
-            CM0 = __builtin_fma(et0, fm, CM0);
-            CMB = __builtin_fma(etb, fm, CMB);
-            DIR = __builtin_fma(wz * u0, etb, DIR);
-            DIRU = __builtin_fma(wz, etb, DIRU);
-          }
-          cp0 = CP0; cm0 = CM0; cpb[t] = CPB; cmb[t] = CMB; dir[t] = DIR; diru[t] = DIRU;
-          Ssfc = Rsfc * DIR;  // :89 (used by the surface row only)
-        } else {
-          const double gam1 = 2.0 - w0_in * (1.0 + gt_in);  // :195-201
-          const double gam2 = w0_in * (1.0 - gt_in);
-          const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
-          G[t] = gam2 / (gam1 + lam);
-          X[t] = fexp(-lam * tau_in);
-          const double bpl_bot = planck(avg_freq, i + 1 == nz ? *Tsfc : Tcol[nz - 2 - i]);  // radiate.f90:65-69
-          double b0n, b1n;  // :216-227
-          if (tau_in <= p.ir_tau_min) {
-            b0n = 0.5 * (bpl_top + bpl_bot);
-            b1n = 0.0;
-          } else {
-            b0n = bpl_top;
-            b1n = (bpl_bot - b0n) / tau_in;
-          }
-          const double norm = 2.0 * PI * 0.5;
-          const double r = 1.0 / (gam1 + gam2);
-          cp0 = norm * (b0n + b1n * (r));  // :229-232
-          cpb[t] = norm * (b0n + b1n * (tau_in + r));
-          cm0 = norm * (b0n + b1n * (-r));
-          cmb[t] = norm * (b0n + b1n * (tau_in - r));
-          if (p.has_hard_surface) {  // :236-247 (used by the surface row only)
-            Ssfc = p.emissivity[ll] * PI * bpl_bot;
-          } else {
-            const double b1_bot = (tau_in <= p.ir_tau_min) ? 0.0 : (bpl_bot - bpl_top) / tau_in;
-            Ssfc = PI * (bpl_bot + 0.5 * b1_bot);
-          }
-          bpl_top = bpl_bot;
-        }
-        const E4 v = make_e(G[t], X[t]);
-        if (t == 0) {
-          cp0_top = cp0;
-          // row 0: TOA row (:93-96) or the flux condition "-Din + e1 y1 - e2 y2 = -cm0"
-          const double A = (a == 0) ? 0.0 : -1.0;
-          const double r = rcp_nr(v.e1 - A * cp);
-          cp = (-v.e2) * r; dp = ((0.0 - cm0) - A * dp) * r; lp = (-A * lp) * r;
-          rc[0] = cp; rd[0] = dp; rl[0] = lp;
-        } else {
-          // row 2t-1 (layers t-1, t)
-          double A = v.e2 * u.e1 - u.e3 * v.e4, B = u.e2 * v.e2 - u.e4 * v.e4, D = v.e1 * v.e4 - v.e2 * v.e3;
-          double E = v.e2 * (cp0 - cpb_u) - v.e4 * (cm0 - cmb_u);
-          double r = rcp_nr(B - A * cp);
-          double cn = D * r, dn = (E - A * dp) * r, ln = (-A * lp) * r;
-          rc[2 * t - 1] = cn; rd[2 * t - 1] = dn; rl[2 * t - 1] = ln;
-          // row 2t
-          A = u.e2 * u.e3 - u.e4 * u.e1; B = u.e1 * v.e1 - u.e3 * v.e3; D = u.e3 * v.e4 - u.e1 * v.e2;
-          E = u.e3 * (cp0 - cpb_u) + u.e1 * (cmb_u - cm0);
-          r = rcp_nr(B - A * cn);
-          cp = D * r; dp = (E - A * dn) * r; lp = (-A * ln) * r;
-          rc[2 * t] = cp; rd[2 * t] = dp; rl[2 * t] = lp;
-        }
-        if (t == len - 1) {
-          // last row of the chunk: surface row (:113-117) or "e1 y1 + e2 y2 - Uin = -cpb"
-          double A, B, D, E;
-          if (b == nz) { A = v.e1 - Rsfc * v.e3; B = v.e2 - Rsfc * v.e4; D = 0.0; E = Ssfc - cpb[t] + Rsfc * cmb[t]; }
-          else { A = v.e1; B = v.e2; D = -1.0; E = 0.0 - cpb[t]; }
-          const double r = rcp_nr(B - A * cp);
-          const double cn = D * r, dn = (E - A * dp) * r, ln = (-A * lp) * r;
-          rc[2 * t + 1] = cn; rd[2 * t + 1] = dn; rl[2 * t + 1] = ln;
-        }
-        u = v; cpb_u = cpb[t]; cmb_u = cmb[t];
-      }
-    }
-  }
-  TSTAMP(2);
-  // ---- upward: y_r = alpha_r + beta_r*Uin + gamma_r*Din   (alpha -> rd, beta -> rc, gamma -> rl)
-  double aB0 = 0, bB0 = 0, gB0 = 0, aB1 = 0, bB1 = 0, gB1 = 0;
-  {
-    double al = 0.0, be = 1.0, ga = 0.0;
-#pragma unroll
-    for (int r = 2 * LMAX - 1; r >= 0; r--) {
-      if (r < 2 * len) {
-        const double cc = rc[r], dd = rd[r], lc = rl[r];
-        al = dd - cc * al; be = -cc * be; ga = -lc - cc * ga;
-        rd[r] = al; rc[r] = be; rl[r] = ga;
-        if (r == 2 * len - 1) { aB1 = al; bB1 = be; gB1 = ga; }
-        if (r == 2 * len - 2) { aB0 = al; bB0 = be; gB0 = ga; }
-      }
-    }
-  }
-  // ---- the chunk as an affine map of (Din, Uin); empty chunks are the identity
-  double uS = 0.0, uD = 0.0, uU = 1.0, dS = 0.0, dD = 1.0, dU = 0.0;
-  if (len > 0) {
-    const E4 ea = make_e(G[0], X[0]);
-    double Gb = G[0], Xb = X[0], cmbb = cmb[0];
-#pragma unroll
-    for (int t = 1; t < LMAX; t++)
-      if (t == len - 1) { Gb = G[t]; Xb = X[t]; cmbb = cmb[t]; }
-    const E4 eb = make_e(Gb, Xb);
-    // up-flux leaving through the chunk's top (fup(1) form, :143), down-flux through its bottom (:147)
-    uS = rd[0] * ea.e3 - rd[1] * ea.e4 + cp0_top; uD = rl[0] * ea.e3 - rl[1] * ea.e4; uU = rc[0] * ea.e3 - rc[1] * ea.e4;
-    dS = aB0 * eb.e3 + aB1 * eb.e4 + cmbb; dD = gB0 * eb.e3 + gB1 * eb.e4; dU = bB0 * eb.e3 + bB1 * eb.e4;
-  }
-  TSTAMP(3);
-  // ---- bottom-up suffix scan of the projective reflectance recursion
-  M7 P;
-  P.m00 = uU * dD - uD * dU; P.m02 = uD; P.m10 = uU * dS - uS * dU; P.m11 = uU; P.m12 = uS; P.m20 = -dU; P.m22 = 1.0;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const M7 R = m7_shfl_down(P, d);
-    if (lane + d < 64) P = m7_mul(P, R);
-  }
-  TSTAMP(4);
-  // P applied to (0,0,1): state above chunk `lane`; the state below it lives one lane down
-  const double rinv = rcp_nr(P.m22);
-  const double rho_above = P.m02 * rinv, sig_above = P.m12 * rinv;
-  double rho = __shfl_down(rho_above, 1), sig = __shfl_down(sig_above, 1);
-  if (lane == 63) { rho = 0.0; sig = 0.0; }
-  // ---- top-down affine scan: Din_{q+1} = alpha_q + beta_q*Din_q
-  const double mm = rcp_nr(1.0 - rho * dU);
-  double sa = dS + dU * mm * (rho * dS + sig);
-  double sb = dD * (1.0 + dU * mm * rho);
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double pa = __shfl_up(sa, d), pb = __shfl_up(sb, d);
-    if (lane >= d) { sa = sa + sb * pa; sb = sb * pb; }
-  }
-  double Din = __shfl_up(sa, 1);
-  if (lane == 0) Din = 0.0;
-  const double Uin = mm * (rho * dS + sig + rho * dD * Din);
-
-  TSTAMP(5);
-  // ---- level fluxes (:143-148, :288-293), mean intensity (:135-140), g-point weight
-  double *sFu = lds + (size_t)(0 * TSW_COLS + wave) * nl;
-  double *sFd = lds + (size_t)(1 * TSW_COLS + wave) * nl;
-  double *sAm = lds + (size_t)(2 * TSW_COLS + wave) * nl;
-#pragma unroll
-  for (int t = 0; t < LMAX; t++) {
-    if (t < len) {
-      const int i = a + t;
-      const E4 e = make_e(G[t], X[t]);
-      const double y1 = rd[2 * t] + rc[2 * t] * Uin + rl[2 * t] * Din;
-      const double y2 = rd[2 * t + 1] + rc[2 * t + 1] * Uin + rl[2 * t + 1] * Din;
-      sFu[i + 1] = wcol * (y1 * e.e1 + y2 * e.e2 + cpb[t]);
-      sFd[i + 1] = wcol * ((y1 * e.e3 + y2 * e.e4 + cmb[t]) + dir[t]);
-      sAm[i + 1] = wcol * (inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + cpb[t] + cmb[t]) + diru[t]);
-      if (i == 0) {
-        const double top = (y1 * e.e3 - y2 * e.e4) + cp0_top;
-        sFu[0] = wcol * top;
-        sFd[0] = wcol * lvl0_dn;
-        sAm[0] = wcol * (inv_u1 * top + lvl0_am);
-      }
-    }
-  }
-  TSTAMP(6);
-  __syncthreads();
-  TSTAMP(7);
-  // ---- sum over the block's g-points, unit factors (radiate.f90:167-180), reversal (:140-154)
-  const bool split = p.accumulate != 0;
-  double scale = 1.0;
-  if (solar) scale = p.photons_sol[ll] * p.photon_scale_factor;  // clima_radtran.f90:302
-  for (int n = threadIdx.x; n < nl; n += blockDim.x) {
-    double fu = 0.0, fd = 0.0, am = 0.0;
-#pragma unroll
-    for (int w = 0; w < TSW_COLS; w++) {
-      fu = fu + lds[(size_t)(0 * TSW_COLS + w) * nl + n];
-      fd = fd + lds[(size_t)(1 * TSW_COLS + w) * nl + n];
-      am = am + lds[(size_t)(2 * TSW_COLS + w) * nl + n];
-    }
-    const size_t o = (size_t)ll * nl + (nz - n);
-    if (solar) {
-      fu = fu * scale * p.diurnal_fac;
-      fd = fd * scale * p.diurnal_fac;
-      am = am * scale * p.diurnal_fac;
-      am = am * p.am_f1[ll];
-      am = am * p.am_f2[ll] * p.am_dw[ll];
-      if (split) { atomicAdd(&p.sol_fup_a[o], fu); atomicAdd(&p.sol_fdn_a[o], fd); atomicAdd(&p.sol_amean[o], am); }
-      else { p.sol_fup_a[o] = fu; p.sol_fdn_a[o] = fd; p.sol_amean[o] = am; }
-    } else {
-      const size_t ob = o + (size_t)bz * p.b_out;
-      if (split) { atomicAdd(&p.ir_fup_a[ob], fu); atomicAdd(&p.ir_fdn_a[ob], fd); }
-      else { p.ir_fup_a[ob] = fu; p.ir_fdn_a[ob] = fd; }
-    }
-  }
-  if (gy == 0 && p.col_base == 0 && p.b_out == 0) {
-    double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
-    for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = ld_opr<COHERENT>(&p.tau_band[(size_t)l * nz + (nz - 1 - i)]);
-  }
-  TSTAMP(8);
-#undef TSTAMP
-}
-
 // ------------------------------------------------------------------------------------
-// twostream_p_body: the wave-per-column solve as straight-line code, used by k_fused.  Same
-// equations, decomposition and scans as twostream_w_body.  The difference is the lane whose chunk
-// holds fewer than L layers: its L slots are filled from the top with zero-thickness layers
-// (tau = 0, w0 = 0: transparent, and with the same Planck value on both faces they emit nothing);
-// its real layers sit below them.  A zero-thickness layer hands both fluxes through unchanged, so
-// the column's solution is the same (to rounding: its rows have pivots of 2), and every lane runs
-// the same L layers.  With no per-layer branch there are no exec-mask regions, no merge copies
-// and no zero initialisation of skipped layers, the zenith angles become the outer loop (their
-// constants are fetched once, the direct-beam transmission is a running product down the chunk)
-// and the whole coefficient phase is one block for the scheduler.  In this code a wave's run
-// time follows its instruction count (see fast_exp), and those were a third of it.
+// twostream_p_body: the solve of one column by one wave (see above), as straight-line code.
+// A lane whose chunk holds fewer than L layers fills its L slots from the top with zero-thickness
+// layers (tau = 0, w0 = 0: transparent, and with the same Planck value on both faces they emit
+// nothing); its real layers sit below them.  A zero-thickness layer hands both fluxes through
+// unchanged, so the column's solution is the same (to rounding: its rows have pivots of 2), and
+// every lane runs the same L layers.  With no per-layer branch there are no exec-mask regions, no
+// merge copies and no zero initialisation of skipped layers, the zenith angles become the outer
+// loop (their constants are fetched once, the direct-beam transmission is a running product down
+// the chunk) and the whole coefficient phase is one block for the scheduler.  In this code a
+// wave's run time follows its instruction count (see fast_exp); an earlier form that branched on
+// every layer's presence spent a third of its instructions on that bookkeeping.
 // ------------------------------------------------------------------------------------
 template <int L, bool SOLAR, int NZMAX, bool COHERENT, bool RESK>
 __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const int bin_local, double *lds,
@@ -2266,13 +1906,8 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 template <int LMAX>
 __global__ __launch_bounds__(64 * TSW_COLS, LMAX > 4 ? 2 : 1) void k_twostream_w(TwoStreamParams p) {
   extern __shared__ __align__(16) double lds[];  // [3][TSW_COLS][nz+1] weighted level values
-  if constexpr (LMAX <= 4) {  // the straight-line form, as in k_fused: the two launch forms give the same bits
-    if ((int)blockIdx.x < p.n_sol) twostream_p_body<LMAX, true, 0, false, false>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
-    else twostream_p_body<LMAX, false, 0, false, false>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
-  } else {
-    if ((int)blockIdx.x < p.n_sol) twostream_w_body<LMAX, true, false, 0>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
-    else twostream_w_body<LMAX, false, false, 0>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
-  }
+  if ((int)blockIdx.x < p.n_sol) twostream_p_body<LMAX, true, 0, false, false>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
+  else twostream_p_body<LMAX, false, 0, false, false>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
@@ -2305,13 +1940,12 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   const int grid = p.n_sol + p.n_ir;
   if (grid <= 0) return true;
   if (groups > 1 && !zeroed) ts_zero_outputs(p, s);
+  using Kern = void (*)(TwoStreamParams);
+  static const Kern kern[8] = {k_twostream_w<1>, k_twostream_w<2>, k_twostream_w<3>, k_twostream_w<4>,
+                               k_twostream_w<5>, k_twostream_w<6>, k_twostream_w<7>, k_twostream_w<8>};
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void *)k_twostream_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_twostream_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_twostream_w<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_twostream_w<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_twostream_w<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const Kern k : kern) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   // Up to two g-point groups go in one launch: two partial sums added into a zeroed output
@@ -2323,11 +1957,7 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
     p.col_base = g0 * TSW_COLS;
     p.accumulate = groups > 1 ? 1 : 0;
     const dim3 g(grid, per_launch, p.b_ncol > 0 ? p.b_ncol : 1);
-    if (lmax <= 1) hipLaunchKernelGGL((k_twostream_w<1>), g, blk, lds, s, p);
-    else if (lmax <= 2) hipLaunchKernelGGL((k_twostream_w<2>), g, blk, lds, s, p);
-    else if (lmax <= 3) hipLaunchKernelGGL((k_twostream_w<3>), g, blk, lds, s, p);
-    else if (lmax <= 4) hipLaunchKernelGGL((k_twostream_w<4>), g, blk, lds, s, p);
-    else hipLaunchKernelGGL((k_twostream_w<8>), g, blk, lds, s, p);
+    hipLaunchKernelGGL(kern[lmax - 1], g, blk, lds, s, p);  // layer slots per lane = ceil(nz/64)
   }
   return true;
 }
@@ -2361,7 +1991,7 @@ void launch_test_wscan(const double *a, const double *b, double *out, int nwaves
 // bin and shared by the g-point waves through LDS), the linear source terms, the right-hand
 // side sweeps and two affine wave scans: ~200 instructions per lane instead of ~1700.
 //
-// Same decomposition as twostream_w_body (lane q owns layers [q nz/64, (q+1) nz/64), flux
+// Same decomposition as twostream_p_body (lane q owns layers [q nz/64, (q+1) nz/64), flux
 // boundary conditions per chunk); written as
 //     y_r = alpha_r + beta_r Uin + gamma_r Din            inside a chunk,
 //     sig_above_q = A_q + Bq sig_above_{q+1}              bottom-up (source seen from above),
