@@ -115,14 +115,19 @@ def test_separate_launch_form_at_full_size(nominal):
     assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(a[1])
 
 
-def test_fused_handoff_is_fresh_under_alternating_columns(nominal):
+@pytest.mark.parametrize("nz", [200, 100, 150])
+def test_fused_handoff_is_fresh_under_alternating_columns(nominal, nz):
     """The fused grid hands the opacities from producer to consumer blocks inside one launch
     (device-scope stores / loads, no cache-wide fences).  A stale read would return the PREVIOUS
     call's opacities, so alternate between different columns: every call must reproduce the
-    separate-launch results of its own column (opacities bit for bit, fluxes to rounding)."""
+    separate-launch results of its own column (opacities bit for bit, fluxes to rounding).
+    nz = 200, 100, 150: the fused grid's two-stream part with 4, 2 and 3 layer slots per lane."""
     from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
     tb, r, col = nominal
-    cols = [col] + S.perturbed_columns(2, 200, seed=11)
+    if nz != 200:
+        r, col = Radtran(tb, nz, 8, 0.15), S.modern_earth_column(nz)
+    cols = [col] + S.perturbed_columns(2, nz, seed=11)
 
     def run(c):
         r.upload_column(*c.args())

@@ -2,16 +2,17 @@
 """Developer tool: hammer config 2 with ALTERNATING columns (so that a stale read in the fused
 kernel's block-to-block hand-off -- which would return the previous call's opacities -- cannot
 hide behind identical inputs) and require bitwise-identical level fluxes, spectra and opacities
-for every repeat of the same column.  Usage: gpu_stress.py [calls]"""
+for every repeat of the same column.  Usage: gpu_stress.py [calls] [nz]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from clima_amd import synthetic as S
 from clima_amd.radtran import Radtran
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+nz = int(sys.argv[2]) if len(sys.argv) > 2 else 200   # 65..256: the fused grid with 2, 3 or 4 layer slots per lane
 tb = S.modern_earth_tables()
-cols = [S.modern_earth_column(200)] + S.perturbed_columns(2, 200, seed=11)
-r = Radtran(tb, 200, 8, 0.15)
+cols = [S.modern_earth_column(nz)] + S.perturbed_columns(2, nz, seed=11)
+r = Radtran(tb, nz, 8, 0.15)
 
 def run(c, spectra=False, opr=False):
     r.upload_column(*c.args())
