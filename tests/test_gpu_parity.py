@@ -165,6 +165,17 @@ def test_multiple_zenith_angles_and_scalars(O, small_tables):
     _compare(r, o, S.modern_earth_column(40))
 
 
+@pytest.mark.parametrize("nz,nzen", [(40, 12), (100, 12), (100, 3), (200, 16), (150, 1), (300, 10), (450, 5)])
+def test_zenith_counts_across_launch_forms(O, nz, nzen):
+    # 1..16 zenith angles (the fused grid unrolls the first 8 and loops over the rest) on columns
+    # that take the separate launches (40 layers), the fused grid with 2, 3 and 4 layer slots per
+    # lane (100, 150, 200), and the 5- and 8-slot stand-alone kernels (300, 450)
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=12, seed=500 + nz + nzen)
+    r, o = _pair(O, tb, nz, nzen, 0.2, diurnal_fac=0.5)
+    _compare(r, o, S.modern_earth_column(nz))
+
+
 def test_no_hard_surface_and_emissivity(O, small_tables):
     from clima_amd import synthetic as S
     r, o = _pair(O, small_tables, 30, 2, 0.2, has_hard_surface=False, ir_tau_min=1e-3)
