@@ -1724,8 +1724,8 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       G[t] = gam2 * rcp_nr(gam1 + lam);
       X[t] = fexp(-lam * tau_in);
       const double bpl_top = bpl[t], bpl_bot = bpl[t + 1];
-      double b0n, b1n;  // :216-227
-      if (tau_in <= p.ir_tau_min) {
+      double b0n, b1n;  // :216-227 (a zero-thickness slot is thin whatever ir_tau_min is set to)
+      if (tau_in <= p.ir_tau_min || t < pad) {
         b0n = 0.5 * (bpl_top + bpl_bot);
         b1n = 0.0;
       } else {
