@@ -2001,12 +2001,10 @@ void launch_test_wscan(const double *a, const double *b, double *out, int nwaves
 // ------------------------------------------------------------------------------------
 constexpr int IRB_WAVES = 8;   // g-point waves per block: the kernel covers ng <= 8
 constexpr int IRB_TILE = 8;    // columns whose Planck values sit in LDS together
-#ifndef IRB_NC
-#define IRB_NC 1               // columns a wave works on at once; 2 interleaves their dependent chains but spills
-                               // ~100 more registers and measured slower (13.5 vs 10.0 us per column)
-#endif
+// (working on two columns at once, to interleave their dependent chains, spilled ~100 more
+// registers and measured slower: 13.5 vs 10.0 us per column)
 
-template <int LMAX>
+template <int L>
 __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStreamParams p, int ncol, int cols_per_block) {
   extern __shared__ __align__(16) double lds[];
   const int nz = p.nz, ng = p.ng, nl = nz + 1;
@@ -2021,94 +2019,82 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
   const double *tauL = p.tau + ((size_t)l * ng + cg) * nz;
   const double *w0L = p.w0 + ((size_t)l * ng + cg) * nz;
   const double *gL = p.g + (size_t)l * nz;
-  const int a = (lane * nz) >> 6, b = ((lane + 1) * nz) >> 6, len = b - a;
+  // slots as in twostream_p_body: L per lane, a short chunk padded from the top with
+  // zero-thickness layers, so that nothing below branches on the chunk's length
+  const int a = (lane * nz) >> 6, b = ((lane + 1) * nz) >> 6, pad = L - (b - a);
+  const bool is_toa = lane == 0, is_sfc = lane == 63, empty = pad == L;
   const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);
   const bool hard = p.has_hard_surface != 0;
   const double emis = hard ? p.emissivity[ll] : 0.0;
   const double Rsfc = hard ? 1.0 - emis : 0.0;  // twostream.f90:186-190
 
   // ---- temperature-independent part -------------------------------------------------
-  double G[LMAX], X[LMAX], itau[LMAX], rq[LMAX], tauv[LMAX];
-  double rr[2 * LMAX], ar[2 * LMAX], cc[2 * LMAX], be[2 * LMAX], ga[2 * LMAX];
+  double G[L], X[L], itau[L], rq[L], tauv[L];
+  double rr[2 * L], ar[2 * L], cc[2 * L], be[2 * L], ga[2 * L];
   {
-    double cp = 0.0, lp = -1.0;
-    E4 u = make_e(0.0, 0.0);
 #pragma unroll
-    for (int t = 0; t < LMAX; t++) {
-      G[t] = X[t] = itau[t] = rq[t] = tauv[t] = 0.0;
-      rr[2 * t] = rr[2 * t + 1] = ar[2 * t] = ar[2 * t + 1] = cc[2 * t] = cc[2 * t + 1] = 0.0;
-      be[2 * t] = be[2 * t + 1] = ga[2 * t] = ga[2 * t + 1] = 0.0;
-      if (t < len) {
-        const int i = a + t;
-        const double tau_in = tauL[i], w0_in = w0L[i], gt_in = gL[i];
-        const double gam1 = 2.0 - w0_in * (1.0 + gt_in);  // :195-201
-        const double gam2 = w0_in * (1.0 - gt_in);
-        const double lam = sqrt(gam1 * gam1 - gam2 * gam2);
-        G[t] = gam2 / (gam1 + lam);
-        X[t] = fast_exp(-lam * tau_in);
-        itau[t] = (tau_in <= p.ir_tau_min) ? 0.0 : 1.0 / tau_in;  // 0 marks the thin-layer source rule (:216-227)
-        rq[t] = 1.0 / (gam1 + gam2);
-        tauv[t] = tau_in;
-        const E4 v = make_e(G[t], X[t]);
-        if (t == 0) {
-          const double A = (a == 0) ? 0.0 : -1.0;
-          const double r = rcp_nr(v.e1 - A * cp);
-          rr[0] = r; ar[0] = A * r;
-          cp = (-v.e2) * r; lp = (-A * lp) * r;
-          cc[0] = cp; ga[0] = lp;
-        } else {
-          double A = v.e2 * u.e1 - u.e3 * v.e4, B = u.e2 * v.e2 - u.e4 * v.e4, D = v.e1 * v.e4 - v.e2 * v.e3;
-          double r = rcp_nr(B - A * cp);
-          rr[2 * t - 1] = r; ar[2 * t - 1] = A * r;
-          const double cn = D * r, ln = (-A * lp) * r;
-          cc[2 * t - 1] = cn; ga[2 * t - 1] = ln;
-          A = u.e2 * u.e3 - u.e4 * u.e1; B = u.e1 * v.e1 - u.e3 * v.e3; D = u.e3 * v.e4 - u.e1 * v.e2;
-          r = rcp_nr(B - A * cn);
-          rr[2 * t] = r; ar[2 * t] = A * r;
-          cp = D * r; lp = (-A * ln) * r;
-          cc[2 * t] = cp; ga[2 * t] = lp;
-        }
-        if (t == len - 1) {
-          double A, B, D;
-          if (b == nz) { A = v.e1 - Rsfc * v.e3; B = v.e2 - Rsfc * v.e4; D = 0.0; }
-          else { A = v.e1; B = v.e2; D = -1.0; }
-          const double r = rcp_nr(B - A * cp);
-          rr[2 * t + 1] = r; ar[2 * t + 1] = A * r;
-          cc[2 * t + 1] = D * r; ga[2 * t + 1] = (-A * lp) * r;
-        }
-        u = v;
-      }
+    for (int t = 0; t < L; t++) {
+      const bool real = t >= pad;
+      const int i = min(max(a + t - pad, 0), nz - 1);
+      const double tau_in = real ? tauL[i] : 0.0, w0_in = real ? w0L[i] : 0.0, gt_in = real ? gL[i] : 0.0;
+      const double gam1 = 2.0 - w0_in * (1.0 + gt_in);  // :195-201
+      const double gam2 = w0_in * (1.0 - gt_in);
+      const double lam = sqrt_nr(gam1 * gam1 - gam2 * gam2);
+      G[t] = gam2 * rcp_nr(gam1 + lam);
+      X[t] = fast_exp(-lam * tau_in);
+      itau[t] = (tau_in <= p.ir_tau_min || !real) ? 0.0 : 1.0 / tau_in;  // 0 marks the thin-layer source rule (:216-227)
+      rq[t] = rcp_nr(gam1 + gam2);
+      tauv[t] = tau_in;
+    }
+    E4 u = make_e(G[0], X[0]);
+    double cp, lp;
+    {
+      const double A = is_toa ? 0.0 : -1.0;
+      const double r = rcp_nr(u.e1);
+      rr[0] = r; ar[0] = A * r;
+      cp = (-u.e2) * r; lp = A * r;
+      cc[0] = cp; ga[0] = lp;
+    }
+#pragma unroll
+    for (int t = 1; t < L; t++) {
+      const E4 v = make_e(G[t], X[t]);
+      double A = v.e2 * u.e1 - u.e3 * v.e4, B = u.e2 * v.e2 - u.e4 * v.e4, D = v.e1 * v.e4 - v.e2 * v.e3;
+      double r = rcp_nr(B - A * cp);
+      rr[2 * t - 1] = r; ar[2 * t - 1] = A * r;
+      const double cn = D * r, ln = (-A * lp) * r;
+      cc[2 * t - 1] = cn; ga[2 * t - 1] = ln;
+      A = u.e2 * u.e3 - u.e4 * u.e1; B = u.e1 * v.e1 - u.e3 * v.e3; D = u.e3 * v.e4 - u.e1 * v.e2;
+      r = rcp_nr(B - A * cn);
+      rr[2 * t] = r; ar[2 * t] = A * r;
+      cp = D * r; lp = (-A * ln) * r;
+      cc[2 * t] = cp; ga[2 * t] = lp;
+      u = v;
+    }
+    {
+      const double A = is_sfc ? u.e1 - Rsfc * u.e3 : u.e1;
+      const double B = is_sfc ? u.e2 - Rsfc * u.e4 : u.e2;
+      const double D = is_sfc ? 0.0 : -1.0;
+      const double r = rcp_nr(B - A * cp);
+      rr[2 * L - 1] = r; ar[2 * L - 1] = A * r;
+      cc[2 * L - 1] = D * r; ga[2 * L - 1] = (-A * lp) * r;
     }
   }
   // upward sweep of the Uin / Din coefficients (ga holds the l_r of the downward pass on entry)
-  double bB0 = 0, gB0 = 0, bB1 = 0, gB1 = 0;
   {
     double bev = 1.0, gav = 0.0;
 #pragma unroll
-    for (int r = 2 * LMAX - 1; r >= 0; r--) {
-      if (r < 2 * len) {
-        const double c_ = cc[r], lc = ga[r];
-        bev = -c_ * bev; gav = -lc - c_ * gav;
-        be[r] = bev; ga[r] = gav;
-        if (r == 2 * len - 1) { bB1 = bev; gB1 = gav; }
-        if (r == 2 * len - 2) { bB0 = bev; gB0 = gav; }
-      }
+    for (int r = 2 * L - 1; r >= 0; r--) {
+      const double c_ = cc[r], lc = ga[r];
+      bev = -c_ * bev; gav = -lc - c_ * gav;
+      be[r] = bev; ga[r] = gav;
     }
   }
-  // the chunk as a map of (Din, Uin): temperature-independent entries
-  double uD = 0.0, uU = 1.0, dD = 1.0, dU = 0.0;
-  double ea3 = 0.0, ea4 = 0.0, eb3 = 0.0, eb4 = 0.0;
-  if (len > 0) {
-    const E4 ea = make_e(G[0], X[0]);
-    double Gb = G[0], Xb = X[0];
-#pragma unroll
-    for (int t = 1; t < LMAX; t++)
-      if (t == len - 1) { Gb = G[t]; Xb = X[t]; }
-    const E4 eb = make_e(Gb, Xb);
-    ea3 = ea.e3; ea4 = ea.e4; eb3 = eb.e3; eb4 = eb.e4;
-    uD = ga[0] * ea3 - ga[1] * ea4; uU = be[0] * ea3 - be[1] * ea4;
-    dD = gB0 * eb3 + gB1 * eb4; dU = bB0 * eb3 + bB1 * eb4;
-  }
+  // the chunk as a map of (Din, Uin): temperature-independent entries (a chunk without a real
+  // layer is the identity exactly)
+  const E4 ea = make_e(G[0], X[0]), eb = make_e(G[L - 1], X[L - 1]);
+  const double ea3 = ea.e3, ea4 = ea.e4, eb3 = eb.e3, eb4 = eb.e4;
+  const double uD = empty ? 0.0 : ga[0] * ea3 - ga[1] * ea4, uU = empty ? 1.0 : be[0] * ea3 - be[1] * ea4;
+  const double dD = empty ? 1.0 : ga[2 * L - 2] * eb3 + ga[2 * L - 1] * eb4, dU = empty ? 0.0 : be[2 * L - 2] * eb3 + be[2 * L - 1] * eb4;
   // reflectance seen from above every interface: projective suffix scan of 2x2 matrices
   double rho;
   {
@@ -2130,7 +2116,7 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
   // scan coefficients: sig_above_q = A_q + Bq*sig_above_{q+1};  Din_{q+1} = sa_q + sb_q*Din_q
   // Both scans run over DPP (wscan_*); the bottom-up one is a prefix scan of the lane-reversed
   // data.  Their per-step multipliers live in LDS, one slot per thread and step: they are read
-  // once per column and would otherwise cost 28 VGPRs of a budget that is already spilling.
+  // once per column and would otherwise cost 28 VGPRs.
   double *sStep = sF0 + (size_t)4 * IRB_WAVES * nl + threadIdx.x;  // [2 * WSCAN_STEPS][blockDim.x]
   {
     double st[WSCAN_STEPS];
@@ -2146,6 +2132,10 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
   }
   const double kA = uU * mm * rho;   // A_q = uS + kA*dS
   const double kS = dU * mm;         // sa_q = dS + kS*(rho*dS + sig)
+  // the L+1 faces of the slots: level a for every face of a zero-thickness slot
+  int face[L + 1];
+#pragma unroll
+  for (int s = 0; s <= L; s++) face[s] = a + max(s - pad, 0);
 
   // ---- the columns ---------------------------------------------------------------------
   const int c_begin = (int)blockIdx.z * cols_per_block;
@@ -2160,154 +2150,126 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
       sB[(size_t)cj * nl + n] = planck_fcn(avg_freq, temp);
     }
     __syncthreads();
-    // IRB_NC columns at a time: their dependent chains (sweeps, two 6-step wave scans) interleave
-    for (int cj0 = 0; cj0 < nt; cj0 += IRB_NC) {
-      const double *Bc[IRB_NC];
-      double dd[IRB_NC][2 * LMAX];
-      double cp0_top[IRB_NC], cmb_last[IRB_NC], uS[IRB_NC], dS[IRB_NC], Uin[IRB_NC], Din[IRB_NC];
+    for (int cj = 0; cj < nt; cj++) {
+      const double *Bc = sB + (size_t)cj * nl;
+      double Bf[L + 1];
 #pragma unroll
-      for (int q = 0; q < IRB_NC; q++) {
-        Bc[q] = sB + (size_t)min(cj0 + q, nt - 1) * nl;   // an odd tail repeats the last column (not stored)
-        cp0_top[q] = 0.0; cmb_last[q] = 0.0;
-        double dpv = 0.0, cpb_u = 0.0, cmb_u = 0.0;
-        E4 u = make_e(0.0, 0.0);
-        double Bt = (len > 0) ? Bc[q][a] : 0.0;
+      for (int s = 0; s <= L; s++) Bf[s] = Bc[face[s]];
+      double dd[2 * L], cpbv[L], cmbv[L];
+      double cp0_top, b1n_last = 0.0;
+      {
+        double dpv = 0.0;
+        E4 u = make_e(G[0], X[0]);
 #pragma unroll
-        for (int t = 0; t < LMAX; t++) {
-          dd[q][2 * t] = dd[q][2 * t + 1] = 0.0;
-          if (t < len) {
-            const double Bb = Bc[q][a + t + 1];
-            const bool thin = itau[t] == 0.0;
-            const double b1n = (Bb - Bt) * itau[t];               // :216-227
-            const double b0n = thin ? 0.5 * (Bt + Bb) : Bt;
-            const double cp0 = PI * (b0n + b1n * rq[t]);          // :229-232, norm = 2 pi * 1/2
-            const double cpbv = PI * (b0n + b1n * (tauv[t] + rq[t]));
-            const double cm0 = PI * (b0n - b1n * rq[t]);
-            const double cmbv = PI * (b0n + b1n * (tauv[t] - rq[t]));
+        for (int t = 0; t < L; t++) {
+          const double Bt = Bf[t], Bb = Bf[t + 1];
+          const double b1n = (Bb - Bt) * itau[t];               // :216-227
+          const double b0n = (itau[t] == 0.0) ? 0.5 * (Bt + Bb) : Bt;
+          const double cp0 = PI * (b0n + b1n * rq[t]);          // :229-232, norm = 2 pi * 1/2
+          cpbv[t] = PI * (b0n + b1n * (tauv[t] + rq[t]));
+          const double cm0 = PI * (b0n - b1n * rq[t]);
+          cmbv[t] = PI * (b0n + b1n * (tauv[t] - rq[t]));
+          if (t == 0) {
+            cp0_top = cp0;
+            dpv = (0.0 - cm0) * rr[0];
+            dd[0] = dpv;
+          } else {
             const E4 v = make_e(G[t], X[t]);
-            if (t == 0) {
-              cp0_top[q] = cp0;
-              dpv = (0.0 - cm0) * rr[0];
-              dd[q][0] = dpv;
-            } else {
-              const double E1 = v.e2 * (cp0 - cpb_u) - v.e4 * (cm0 - cmb_u);
-              const double dn = E1 * rr[2 * t - 1] - ar[2 * t - 1] * dpv;
-              dd[q][2 * t - 1] = dn;
-              const double E2 = u.e3 * (cp0 - cpb_u) + u.e1 * (cmb_u - cm0);
-              dpv = E2 * rr[2 * t] - ar[2 * t] * dn;
-              dd[q][2 * t] = dpv;
-            }
-            if (t == len - 1) {
-              double E;
-              if (b == nz) {  // surface row (:236-247)
-                const double Ssfc = hard ? emis * PI * Bb : PI * (Bb + 0.5 * b1n);
-                E = Ssfc - cpbv + Rsfc * cmbv;
-              } else {
-                E = 0.0 - cpbv;
-              }
-              dd[q][2 * t + 1] = E * rr[2 * t + 1] - ar[2 * t + 1] * dpv;
-              cmb_last[q] = cmbv;
-            }
-            u = v; cpb_u = cpbv; cmb_u = cmbv; Bt = Bb;
+            const double E1 = v.e2 * (cp0 - cpbv[t - 1]) - v.e4 * (cm0 - cmbv[t - 1]);
+            const double dn = E1 * rr[2 * t - 1] - ar[2 * t - 1] * dpv;
+            dd[2 * t - 1] = dn;
+            const double E2 = u.e3 * (cp0 - cpbv[t - 1]) + u.e1 * (cmbv[t - 1] - cm0);
+            dpv = E2 * rr[2 * t] - ar[2 * t] * dn;
+            dd[2 * t] = dpv;
+            u = v;
           }
+          if (t == L - 1) b1n_last = b1n;
         }
-        // upward: alpha_r (overwrites dd)
-        double aB0 = 0.0, aB1 = 0.0, al = 0.0;
+        // last row: surface (:236-247) or the flux condition
+        const double Ssfc = hard ? emis * PI * Bf[L] : PI * (Bf[L] + 0.5 * b1n_last);
+        const double E = is_sfc ? Ssfc - cpbv[L - 1] + Rsfc * cmbv[L - 1] : 0.0 - cpbv[L - 1];
+        dd[2 * L - 1] = E * rr[2 * L - 1] - ar[2 * L - 1] * dpv;
+      }
+      // upward: alpha_r (overwrites dd)
+      {
+        double al = 0.0;
 #pragma unroll
-        for (int r = 2 * LMAX - 1; r >= 0; r--) {
-          if (r < 2 * len) {
-            al = dd[q][r] - cc[r] * al;
-            dd[q][r] = al;
-            if (r == 2 * len - 1) aB1 = al;
-            if (r == 2 * len - 2) aB0 = al;
-          }
-        }
-        uS[q] = 0.0; dS[q] = 0.0;
-        if (len > 0) {
-          uS[q] = dd[q][0] * ea3 - dd[q][1] * ea4 + cp0_top[q];
-          dS[q] = aB0 * eb3 + aB1 * eb4 + cmb_last[q];
+        for (int r = 2 * L - 1; r >= 0; r--) {
+          al = dd[r] - cc[r] * al;
+          dd[r] = al;
         }
       }
+      const double uS = empty ? 0.0 : dd[0] * ea3 - dd[1] * ea4 + cp0_top;
+      const double dS = empty ? 0.0 : dd[2 * L - 2] * eb3 + dd[2 * L - 1] * eb4 + cmbv[L - 1];
       // bottom-up: source seen from above each interface (prefix scan in lane-reversed order),
       // then top-down: diffuse flux entering each chunk from above
+      const double sgr = wscan_apply(wave_reverse(uS + kA * dS), [&](int k) { return sStep[(size_t)k * blockDim.x]; });
+      const double sig = wave_reverse(wave_shr1(sgr));   // below chunk q: what chunk q+1 shows from above; 0 under the last
+      const double sa = wscan_apply(dS + kS * (rho * dS + sig),
+                                    [&](int k) { return sStep[(size_t)(WSCAN_STEPS + k) * blockDim.x]; });
+      const double Din = wave_shr1(sa);
+      const double Uin = mm * (rho * dS + sig + rho * dD * Din);
+      // level fluxes (:288-293), g-point weight; consecutive columns alternate the two staging buffers
+      const int buf = cj & 1;
+      double *sFu = sF0 + (size_t)buf * 2 * IRB_WAVES * nl + (size_t)(0 * IRB_WAVES + wave) * nl;
+      double *sFd = sF0 + (size_t)buf * 2 * IRB_WAVES * nl + (size_t)(1 * IRB_WAVES + wave) * nl;
 #pragma unroll
-      for (int q = 0; q < IRB_NC; q++) {
-        const double sgr = wscan_apply(wave_reverse(uS[q] + kA * dS[q]), [&](int k) { return sStep[(size_t)k * blockDim.x]; });
-        const double sig = wave_reverse(wave_shr1(sgr));   // below chunk q: what chunk q+1 shows from above; 0 under the last
-        const double sa = wscan_apply(dS[q] + kS * (rho * dS[q] + sig),
-                                      [&](int k) { return sStep[(size_t)(WSCAN_STEPS + k) * blockDim.x]; });
-        const double d_in = wave_shr1(sa);
-        Din[q] = d_in;
-        Uin[q] = mm * (rho * dS[q] + sig + rho * dD * d_in);
-      }
-      // level fluxes (:288-293), g-point weight; column q of the group goes to staging buffer q
-#pragma unroll
-      for (int q = 0; q < IRB_NC; q++) {
-        const int buf = (IRB_NC == 1) ? (cj0 & 1) : q;   // one column at a time: alternate the two buffers
-        double *sFu = sF0 + (size_t)buf * 2 * IRB_WAVES * nl + (size_t)(0 * IRB_WAVES + wave) * nl;
-        double *sFd = sF0 + (size_t)buf * 2 * IRB_WAVES * nl + (size_t)(1 * IRB_WAVES + wave) * nl;
-#pragma unroll
-        for (int t = 0; t < LMAX; t++) {
-          if (t < len) {
-            const int i = a + t;
-            const E4 e = make_e(G[t], X[t]);
-            const double y1 = dd[q][2 * t] + be[2 * t] * Uin[q] + ga[2 * t] * Din[q];
-            const double y2 = dd[q][2 * t + 1] + be[2 * t + 1] * Uin[q] + ga[2 * t + 1] * Din[q];
-            // the layer-bottom source terms again (cheaper than keeping them across the scans)
-            const double Bt2 = Bc[q][i], Bb2 = Bc[q][i + 1];
-            const double b1n = (Bb2 - Bt2) * itau[t];
-            const double b0n = (itau[t] == 0.0) ? 0.5 * (Bt2 + Bb2) : Bt2;
-            const double cpbv = PI * (b0n + b1n * (tauv[t] + rq[t]));
-            const double cmbv = PI * (b0n + b1n * (tauv[t] - rq[t]));
-            sFu[i + 1] = wcol * (y1 * e.e1 + y2 * e.e2 + cpbv);
-            sFd[i + 1] = wcol * (y1 * e.e3 + y2 * e.e4 + cmbv);
-            if (i == 0) {
-              sFu[0] = wcol * ((y1 * e.e3 - y2 * e.e4) + cp0_top[q]);
-              sFd[0] = 0.0;
-            }
+      for (int t = 0; t < L; t++) {
+        const int i = a + t - pad;
+        const E4 e = make_e(G[t], X[t]);
+        const double y1 = dd[2 * t] + be[2 * t] * Uin + ga[2 * t] * Din;
+        const double y2 = dd[2 * t + 1] + be[2 * t + 1] * Uin + ga[2 * t + 1] * Din;
+        if (t >= pad) {
+          sFu[i + 1] = wcol * (y1 * e.e1 + y2 * e.e2 + cpbv[t]);
+          sFd[i + 1] = wcol * (y1 * e.e3 + y2 * e.e4 + cmbv[t]);
+          if (i == 0) {
+            // the source at the top of the column's first layer
+            const double Bt = Bf[t], Bb = Bf[t + 1];
+            const double b1n = (Bb - Bt) * itau[t];
+            const double b0n = (itau[t] == 0.0) ? 0.5 * (Bt + Bb) : Bt;
+            sFu[0] = wcol * ((y1 * e.e3 - y2 * e.e4) + PI * (b0n + b1n * rq[t]));
+            sFd[0] = 0.0;
           }
         }
       }
       __syncthreads();
       // sum over the g-points (in g order), reversal to ground-first (radiate.f90:140-154)
-      for (int idx = threadIdx.x; idx < IRB_NC * nl; idx += blockDim.x) {
-        const int q = idx / nl, n = idx - q * nl;
-        if (cj0 + q < nt) {
-          const double *sF = sF0 + (size_t)((IRB_NC == 1) ? (cj0 & 1) : q) * 2 * IRB_WAVES * nl;
-          double fu = 0.0, fd = 0.0;
+      for (int n = threadIdx.x; n < nl; n += blockDim.x) {
+        const double *sF = sF0 + (size_t)buf * 2 * IRB_WAVES * nl;
+        double fu = 0.0, fd = 0.0;
 #pragma unroll
-          for (int w = 0; w < IRB_WAVES; w++) {
-            fu = fu + sF[(size_t)(0 * IRB_WAVES + w) * nl + n];
-            fd = fd + sF[(size_t)(1 * IRB_WAVES + w) * nl + n];
-          }
-          const size_t o = (size_t)(c0 + cj0 + q) * p.b_out + (size_t)ll * nl + (nz - n);
-          p.ir_fup_a[o] = fu;
-          p.ir_fdn_a[o] = fd;
+        for (int w = 0; w < IRB_WAVES; w++) {
+          fu = fu + sF[(size_t)(0 * IRB_WAVES + w) * nl + n];
+          fd = fd + sF[(size_t)(1 * IRB_WAVES + w) * nl + n];
         }
+        const size_t o = (size_t)(c0 + cj) * p.b_out + (size_t)ll * nl + (nz - n);
+        p.ir_fup_a[o] = fu;
+        p.ir_fdn_a[o] = fd;
       }
-      if (IRB_NC > 1) __syncthreads();  // the staging buffers are free again (alternated when IRB_NC == 1)
     }
   }
 }
 
 // false when the configuration is outside what the kernel covers: more than 8 g-points, or more
-// than 4 layers per lane (nz > 256) -- the 8-layer instantiation spills ~500 registers and is
-// slower than one full solve per column (measured at nz = 500: 97 vs 37 us per column)
+// than 4 layer slots per lane (nz > 256; an 8-slot instantiation of the earlier form spilled ~500
+// registers and was slower than one full solve per column: 97 vs 37 us per column at nz = 500)
 bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s) {
   const int lmax = (p.nz + 63) / 64;
   if (p.ng > IRB_WAVES || lmax > 4 || p.n_ir <= 0 || ncol <= 0) return false;
   const size_t lds = sizeof(double) * ((size_t)(IRB_TILE + 4 * IRB_WAVES) * ((size_t)p.nz + 1) + 2 * WSCAN_STEPS * 64 * IRB_WAVES);
   if (lds > 160 * 1024) return false;
+  using Kern = void (*)(TwoStreamParams, int, int);
+  static const Kern kern[4] = {k_twostream_ir_batch<1>, k_twostream_ir_batch<2>, k_twostream_ir_batch<3>, k_twostream_ir_batch<4>};
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void *)k_twostream_ir_batch<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const Kern k : kern) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   // enough blocks to fill the chip a few times over, each with a worthwhile run of columns
   int cpb = (ncol + 3) / 4;
   if (cpb < IRB_TILE) cpb = std::min(ncol, IRB_TILE);
   const dim3 grid(p.n_ir, 1, (ncol + cpb - 1) / cpb), blk(64 * IRB_WAVES);
-  hipLaunchKernelGGL((k_twostream_ir_batch<4>), grid, blk, lds, s, p, ncol, cpb);
+  hipLaunchKernelGGL(kern[lmax - 1], grid, blk, lds, s, p, ncol, cpb);  // layer slots per lane = ceil(nz/64)
   return true;
 }
 
