@@ -2578,6 +2578,12 @@ void launch_test_exp(const double *x, double *y, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_test_exp, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
 }
 
+__global__ void k_copy(double *dst, const double *src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_copy(double *dst, const double *src, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy, dim3((unsigned)std::min<size_t>((n + 255) / 256, 64)), dim3(256), 0, s, dst, src, n);
+}
 void launch_scale(double *a, size_t n, double f, hipStream_t s) {
   if (n == 0) return;
   int grid = (int)((n + 255) / 256);

@@ -209,6 +209,7 @@ void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t
 int integrate_chunks(int nbins);
 void launch_f_total(int nz, const double *flux_n, double *f_total, hipStream_t s);
 void launch_scale(double *a, size_t n, double f, hipStream_t s);
+void launch_copy(double *dst, const double *src, size_t n, hipStream_t s);  // src may be pinned host memory
 void launch_test_rcp(const double *x, double *y, int n, hipStream_t s);
 void launch_test_wscan(const double *a, const double *b, double *out, int nwaves, hipStream_t s);
 void launch_test_exp(const double *x, double *y, int n, hipStream_t s);
