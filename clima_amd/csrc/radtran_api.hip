@@ -149,6 +149,7 @@ struct Radtran {
   DevBuf<long long> d_stamps;
 #endif
   double *h_col = nullptr;  // pinned staging
+  double *h_col_dev = nullptr;  // the same buffer as the device addresses it (null: not mapped, use the copy engine)
   size_t col_count = 0;
   bool column_has_particles = false;
   bool column_loaded = false;
@@ -580,7 +581,7 @@ void do_upload(Radtran *r, double T_surface, const double *T, const double *P, c
     // 38 KB: a kernel that reads the pinned buffer over PCIe gets the column into HBM 4 us sooner
     // than the copy engine does (CLIMA_HIP_COPY_KERNEL=0 selects hipMemcpyAsync)
     static const bool kcopy = [] { const char *e = getenv("CLIMA_HIP_COPY_KERNEL"); return !(e && e[0] == '0'); }();
-    if (kcopy) launch_copy(r->d_col.p, h, r->col_count, r->stream);
+    if (kcopy && r->h_col_dev) launch_copy(r->d_col.p, r->h_col_dev, r->col_count, r->stream);
     else HIPCHK(hipMemcpyAsync(r->d_col.p, h, sizeof(double) * r->col_count, hipMemcpyHostToDevice, r->stream));
   }
   HIPCHK(hipEventRecord(r->ev_upload, r->stream));
@@ -1015,7 +1016,8 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   r->col_count = 1 + (size_t)3 * nz + (size_t)nz * r->nsp + (size_t)2 * nz * r->np;
   r->d_col.alloc(r->col_count);
   r->d_col.zero();
-  HIPCHK(hipHostMalloc((void **)&r->h_col, sizeof(double) * r->col_count));
+  HIPCHK(hipHostMalloc((void **)&r->h_col, sizeof(double) * r->col_count, hipHostMallocMapped));
+  if (hipHostGetDevicePointer((void **)&r->h_col_dev, r->h_col, 0) != hipSuccess) { r->h_col_dev = nullptr; (void)hipGetLastError(); }
   r->d_log10P.alloc(nz); r->d_cols.alloc((size_t)nz * r->nsp); r->d_foreign.alloc(nz);
   r->d_absw.alloc((size_t)std::max<size_t>(1, r->abs_entries.size()) * nz);
   r->d_src.alloc(nz); r->d_ix.alloc((size_t)(r->nslots + 1) * nz); r->d_q.alloc((size_t)(r->nslots + 1) * nz);
