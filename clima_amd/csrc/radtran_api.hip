@@ -1313,10 +1313,10 @@ void radtran_finish_reduced(void *ptr, char *err) {
   clear_err(err);
   GUARD(r, ptr, err);
   if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
-  TRY
-  launch_f_total(r->nz, r->d_flux_n.p, r->d_f_total.p, r->stream);
+  // f_total = (sol_dn - sol_up) + (ir_dn - ir_up) of the reduced rows is formed on the host when the
+  // results are fetched (fetch_small), like after every call: nothing to launch here, the level
+  // rows just have to be read again
   r->small_valid = false;
-  CATCH(err)
 }
 
 void radtran_stream_get(void *ptr, void **stream) {

@@ -130,7 +130,8 @@ void radtran_set_bin_shard(void *ptr, const int *rank, const int *world, char *e
  * IR and solar sub-ranges */
 void radtran_bin_shard_get(void *ptr, int *op_lo, int *op_n, int *ir_lo, int *ir_n, int *sol_lo,
                            int *sol_n);
-/* after an external all-reduce of the flux buffer: recompute f_total on the device */
+/* after an external all-reduce of the flux buffer: the level rows have changed; f_total is formed
+ * from them when the results are next read */
 void radtran_finish_reduced(void *ptr, char *err);
 /* Column batch (BASELINE.json config 4): ncol independent Radtran%TOA_fluxes calls
  * (src/radtran/clima_radtran.f90:320-342), moved to HBM in one copy and enqueued back to back.
