@@ -1575,11 +1575,12 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   } while (0)
 #else
 #define TSTAMP(k) do { } while (0)
+  (void)tslot;
 #endif
   TSTAMP(0);
   constexpr bool solar = SOLAR;
   // exp with its constants resident in VGPRs where the register budget is there anyway (RESK: the
-  // fused grid, 256 per wave); the stand-alone kernel keeps three waves per SIMD instead
+  // fused grid, 256 per wave); the stand-alone kernels keep their higher occupancy instead
   ExpK K;
   if constexpr (RESK) K.load();
   auto fexp = [&](double x) {
