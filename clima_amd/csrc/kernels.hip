@@ -720,8 +720,10 @@ __global__ __launch_bounds__(64) void k_opacity_generic(OpacityParams p, int N2)
   double *s_tk = s_cum + (n2 + 1);    // [ng] running mixture
   double *s_kc = s_tk + ng;           // [ng] new species
   double *s_out = s_kc + ng;          // [ng]
-  int *s_idx = (int *)(s_out + ng);   // [N2]
+  double *s_wxy = s_out + ng;         // [n2] weights of the pairs
+  int *s_idx = (int *)(s_wxy + n2);   // [N2]
   const int lane = threadIdx.x;
+  for (int m = lane; m < n2; m += 64) s_wxy[m] = p.wxy[m];
   const ColumnDev &c = p.col;
   const long t = blockIdx.x;
   const int l = p.bin_lo + (int)(t / nz);
@@ -817,10 +819,28 @@ __global__ __launch_bounds__(64) void k_opacity_generic(OpacityParams p, int N2)
         __syncthreads();
       }
     }
-    if (lane == 0) {
-      double cum = 0.0;
-      s_cum[0] = 0.0;
-      for (int m = 0; m < n2; m++) { cum = cum + p.wxy[s_idx[m]]; s_cum[m + 1] = cum; }
+    {
+      // weights_to_bins (clima_eqns.f90:43-54): cumulative weights in rank order.  Every lane sums a
+      // run of consecutive ranks, an exclusive wave scan of the run totals gives its offset (a
+      // serial sum over all ng^2 ranks by one lane was 95 % of this kernel's time at ng = 16)
+      const int seg = (N2 + 63) / 64;
+      double tot = 0.0;
+      for (int q = 0; q < seg; q++) {
+        const int m = lane * seg + q;
+        if (m < n2) tot = tot + s_wxy[s_idx[m]];
+      }
+      double incl = tot;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double nb = __shfl_up(incl, d);
+        if (lane >= d) incl = incl + nb;
+      }
+      double cum = incl - tot;
+      if (lane == 0) { cum = 0.0; s_cum[0] = 0.0; }
+      for (int q = 0; q < seg; q++) {
+        const int m = lane * seg + q;
+        if (m < n2) { cum = cum + s_wxy[s_idx[m]]; s_cum[m + 1] = cum; }
+      }
     }
     __syncthreads();
     if (lane < ng) {
@@ -868,7 +888,7 @@ bool launch_opacity(const OpacityParams &p, hipStream_t s) {
     if (total <= 0) return true;
     int N2 = 2;
     while (N2 < p.ng * p.ng) N2 <<= 1;
-    const size_t lds = sizeof(double) * ((size_t)N2 + p.ng * p.ng + 1 + 3 * p.ng) + sizeof(int) * (size_t)N2;
+    const size_t lds = sizeof(double) * ((size_t)N2 + 2 * p.ng * p.ng + 1 + 3 * p.ng) + sizeof(int) * (size_t)N2;
     hipLaunchKernelGGL(k_opacity_generic, dim3((unsigned)total), dim3(64), lds, s, p, N2);
     return true;
   }
