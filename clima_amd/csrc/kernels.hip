@@ -2321,9 +2321,22 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
     if (threadIdx.x == 0) __hip_atomic_store(&fp.done[blockIdx.x], fp.call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  const int nb = ts.n_sol + ts.n_ir;
   const int b = (int)blockIdx.x - fp.n_op;
-  const int gy = b / nb, bl = b - gy * nb;
+  int gy, bl;
+  {
+    // Dispatch order of the two-stream blocks = block index order, so the index is mapped to work by
+    // readiness: first the solar bins whose opacities come out of the first residency round of
+    // opacity blocks (both g-point groups), then the IR bins (all of them are in that round or
+    // early in the second), last the solar bins of the second round.  A block whose opacities are
+    // not out yet holds its slot while it waits; in plain (group, channel, bin) order the late solar
+    // bins of group 0 sat in front of ready IR work (-0.8 us per call).
+    const int nS = ts.n_sol, nI = ts.n_ir, E = fp.sol_early, Lt = nS - E;
+    const int seg[6] = {E, E, nI, nI, Lt, Lt};
+    int r = b, k = 0;
+    while (k < 5 && r >= seg[k]) { r -= seg[k]; k++; }
+    gy = k & 1;
+    bl = k < 2 ? r : k < 4 ? nS + r : E + r;
+  }
   const bool solar = bl < ts.n_sol;
   const int ll = solar ? ts.sol_lo + bl : ts.ir_lo + (bl - ts.n_sol);
   const int l = (solar ? ts.sol_start : ts.ir_start) + ll;
@@ -2389,6 +2402,13 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
   const int nb = ts.n_sol + ts.n_ir;
   fp.n_op = (int)((total + OP_THREADS - 1) / OP_THREADS);
   fp.slots = (ts.nz + 63) / 64;  // 2..4 (fused_supported)
+  {
+    // solar bins (of this shard) whose opacity blocks sit in the first residency round: two blocks per CU
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
+    const long first_round_bins = ((long)2 * cus * OP_THREADS) / op.nz;
+    fp.sol_early = (int)std::min<long>(ts.n_sol, std::max<long>(0, first_round_bins - (long)(ts.sol_start + ts.sol_lo - op.bin_lo)));
+  }
   const int groups = (ts.ng + TSW_COLS - 1) / TSW_COLS;  // 2
   ts.col_base = 0; ts.accumulate = 1;
   const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)ts.nz + 1);

@@ -488,7 +488,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     if (r->fused && pre_zeroed) {
       TwoStreamParams tsf = make_twostream_params(r, col, compute_solar);
       if (fused_supported(op, tsf)) {
-        FusedParams fp{0, pp.call_id, 400000, r->d_done.p, r->d_err.p, 0};
+        FusedParams fp{0, pp.call_id, 400000, r->d_done.p, r->d_err.p, 0, 0};
         KernelTimer t(r, 1);
         fused_done = launch_fused(op, tsf, fp, r->stream);
         t.stop();

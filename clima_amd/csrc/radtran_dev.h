@@ -168,6 +168,7 @@ struct FusedParams {
   int *done;       // [n_op]
   int *err_flag;
   int slots;       // layers per lane of the two-stream part: ceil(nz/64) = 2..4 (launcher)
+  int sol_early;   // solar bins whose opacities the first round of opacity blocks produces (launcher)
 };
 
 struct IntegrateParams {
