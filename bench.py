@@ -34,9 +34,9 @@ KERNELS = ["prep", "opacity", "twostream", "integrate"]
 EVENT_STRIDE = 16  # HIP events around the dominant kernel on every 16th launch of the timed region (first one included)
 # HBM bytes of one k_opacity8 launch on this exact workload from the PMC passes committed under
 # profiles/ (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; bench.py cannot collect counters itself)
-PMC_TRAFFIC_BYTES = {"fused": (2.736e4 + 4.741e4) * 1024.0,      # profiles/r01i_pmc_summary.md, k_fused
+PMC_TRAFFIC_BYTES = {"fused": (2.732e4 + 4.737e4) * 1024.0,      # profiles/r01j_pmc_summary.md, k_fused
                      "opacity": (1.640e4 + 4.681e4) * 1024.0}    # profiles/r01d_pmc_summary.md, k_opacity8
-PMC_TRAFFIC_SOURCE = "FETCH_SIZE + WRITE_SIZE (KiB) of the dominant kernel per launch: profiles/r01i_pmc_summary.md (k_fused), profiles/r01d_pmc_summary.md (k_opacity8)"
+PMC_TRAFFIC_SOURCE = "FETCH_SIZE + WRITE_SIZE (KiB) of the dominant kernel per launch: profiles/r01j_pmc_summary.md (k_fused), profiles/r01d_pmc_summary.md (k_opacity8)"
 
 
 def main():
