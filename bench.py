@@ -86,6 +86,9 @@ def main():
     rad = Radtran(tables, nz, nzen, 0.15)  # tests/test_radtran.f90:35-38
     if dist_on:
         rad.set_bin_shard(rank, world)
+        fake = os.environ.get("CLIMA_BENCH_FAKE_SHARD")   # "rank,world": rehearse one rank's share of an N-GPU step on one GPU
+        if fake and world == 1:
+            rad.set_bin_shard(*[int(x) for x in fake.split(",")])
     rad.upload_column(*col.args())
     flux = rad.flux_tensor() if dist_on else None
     # The all-reduce is ordered against the library's kernels on the device: the library's HIP
