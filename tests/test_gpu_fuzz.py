@@ -38,7 +38,7 @@ def _case(seed):
                        pxs_species=pxs, particles=particles, water_continuum=bool(rng.random() < 0.6),
                        sorted_k=bool(rng.random() < 0.7), seed=int(rng.integers(1, 10**6)),
                        nP=int(rng.integers(2, 12)), nT=int(rng.integers(2, 12)), nT_cia=int(rng.integers(2, 8)))
-    nz = int(rng.choice([1, 2, 4, 7, 16, 33, 64, 90, 128, 129]))
+    nz = int(rng.choice([1, 2, 4, 7, 16, 33, 64, 90, 128, 129, 192, 200, 256, 300]))
     nzen = int(rng.integers(1, 9))
     col = S.modern_earth_column(nz, n_particles=len(particles))
     # push parts of the column outside the (P, T) table ranges and thin / thicken it
@@ -73,7 +73,7 @@ def _yardstick(O, tb, nz, nzen, albedo, col, scalars, surf):
     return max(float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(a))), 1e-300)) for a, b in zip(*outs))
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(160))
 def test_random_inventory_and_column(O, seed):
     from test_gpu_parity import TOL_LEVEL
     tb, nz, nzen, albedo, col, scalars, rng = _case(seed)
