@@ -14,8 +14,39 @@
 // All arithmetic is IEEE binary64.  No MFMA: there is no dense contraction on this path.
 #include "radtran_dev.h"
 #include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace clima {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize = 160 KiB, once per (device, kernel).  false when the
+// runtime refuses it (the error stays in hipGetLastError for the caller to report).
+static bool ensure_max_lds(const void *fn) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void *>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({dev, fn})) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  done.insert({dev, fn});
+  return true;
+}
+// compute units of the current device (256 when the query fails)
+static int device_cus() {
+  static std::mutex mu;
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!cus[dev]) {
+    hipDeviceProp_t pr;
+    cus[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
 
 // Diagnostic build only (-DCLIMA_STAMPS): s_memtime stamps of one wave, written to a buffer
 // nothing else reads.  The production build contains no stamp.
@@ -1198,7 +1229,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_twostream(TwoStreamParams p) {
     Rsfc = p.has_hard_surface ? 1.0 - emis : 0.0;  // :186-190
     const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64
     for (int n = tid; n < nz + 1; n += nt)                        // radiate.f90:65-69
-      s.Bp[n] = planck_fcn(avg_freq, n == nz ? *p.T_surface : p.T[nz - 1 - n]);
+      s.Bp[n] = p.bplanck ? p.bplanck[n] : planck_fcn(avg_freq, n == nz ? *p.T_surface : p.T[nz - 1 - n]);
     __syncthreads();
     const double norm = 2.0 * PI * 0.5;
 #pragma unroll
@@ -1430,12 +1461,10 @@ bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
   const dim3 g(grid, p.ng / nc);
   if (g.y > 1) ts_zero_outputs(p, s);
   if (threads <= 512) {
-    static bool attr512 = false;
-    if (!attr512) { (void)hipFuncSetAttribute((const void *)k_twostream<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr512 = true; }
+    if (!ensure_max_lds((const void *)k_twostream<512, 4>)) return false;
     hipLaunchKernelGGL((k_twostream<512, 4>), g, dim3(threads), lds, s, p);
   } else {
-    static bool attr1024 = false;
-    if (!attr1024) { (void)hipFuncSetAttribute((const void *)k_twostream<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1024 = true; }
+    if (!ensure_max_lds((const void *)k_twostream<1024, 4>)) return false;
     hipLaunchKernelGGL((k_twostream<1024, 4>), g, dim3(threads), lds, s, p);
   }
   return true;
@@ -1729,7 +1758,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     // each of the nz+1 values is computed once per block instead of L+1 times per lane of every wave
     double *sB = lds + (size_t)3 * TSW_COLS * nl;
     for (int n = threadIdx.x; n < nl; n += blockDim.x)  // TOA-first level
-      sB[n] = planck(avg_freq, n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);
+      sB[n] = p.bplanck ? p.bplanck[n] : planck(avg_freq, n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);
     __syncthreads();
     // the L+1 faces of the slots (level a for every face of a zero-thickness slot)
     double bpl[L + 1];
@@ -1952,7 +1981,7 @@ static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
 int twostream_w_groups(int ng) { return (ng + TSW_COLS - 1) / TSW_COLS; }
 
 bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed) {
-  const int lmax = (p.nz + 63) / 64;
+  const int lmax = std::max((p.nz + 63) / 64, p.force_slots);
   if (lmax > 8) return false;
   const int groups = (p.ng + TSW_COLS - 1) / TSW_COLS;
   const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)p.nz + 1);  // level values of the columns + the bin's Planck table
@@ -1964,11 +1993,7 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   using Kern = void (*)(TwoStreamParams);
   static const Kern kern[8] = {k_twostream_w<1>, k_twostream_w<2>, k_twostream_w<3>, k_twostream_w<4>,
                                k_twostream_w<5>, k_twostream_w<6>, k_twostream_w<7>, k_twostream_w<8>};
-  static bool attr = false;
-  if (!attr) {
-    for (const Kern k : kern) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  if (!ensure_max_lds((const void *)kern[lmax - 1])) return false;
   // Up to two g-point groups go in one launch: two partial sums added into a zeroed output
   // are order-independent.  More groups (ng > 8) run as one launch per group on the same
   // stream, each adding a single addend, so results stay bitwise reproducible.
@@ -2168,7 +2193,7 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
       const int cj = idx / nl, n = idx - cj * nl;
       const double *Tc = p.T + (size_t)(c0 + cj) * p.b_T;
       const double temp = (n == nz) ? p.T_surface[(size_t)(c0 + cj) * p.b_Ts] : Tc[nz - 1 - n];  // radiate.f90:65-69
-      sB[(size_t)cj * nl + n] = planck_fcn(avg_freq, temp);
+      sB[(size_t)cj * nl + n] = p.bplanck ? p.bplanck[n] : planck_fcn(avg_freq, temp);
     }
     __syncthreads();
     for (int cj = 0; cj < nt; cj++) {
@@ -2275,17 +2300,13 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
 // than 4 layer slots per lane (nz > 256; an 8-slot instantiation of the earlier form spilled ~500
 // registers and was slower than one full solve per column: 97 vs 37 us per column at nz = 500)
 bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s) {
-  const int lmax = (p.nz + 63) / 64;
+  const int lmax = std::max((p.nz + 63) / 64, p.force_slots);
   if (p.ng > IRB_WAVES || lmax > 4 || p.n_ir <= 0 || ncol <= 0) return false;
   const size_t lds = sizeof(double) * ((size_t)(IRB_TILE + 4 * IRB_WAVES) * ((size_t)p.nz + 1) + 2 * WSCAN_STEPS * 64 * IRB_WAVES);
   if (lds > 160 * 1024) return false;
   using Kern = void (*)(TwoStreamParams, int, int);
   static const Kern kern[4] = {k_twostream_ir_batch<1>, k_twostream_ir_batch<2>, k_twostream_ir_batch<3>, k_twostream_ir_batch<4>};
-  static bool attr = false;
-  if (!attr) {
-    for (const Kern k : kern) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  if (!ensure_max_lds((const void *)kern[lmax - 1])) return false;
   // enough blocks to fill the chip a few times over, each with a worthwhile run of columns
   int cpb = (ncol + 3) / 4;
   if (cpb < IRB_TILE) cpb = std::min(ncol, IRB_TILE);
@@ -2355,7 +2376,7 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
         if (++spins > fp.max_spins) { ok = 0; break; }
       }
     }
-    if (!ok) atomicMax(fp.err_flag, fp.call_id);
+    if (!ok) atomicMax(fp.timeout_flag, fp.call_id);  // its own word: the host re-issues the call unfused
     s_ok = ok;
   }
   __syncthreads();
@@ -2404,8 +2425,7 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
   fp.slots = (ts.nz + 63) / 64;  // 2..4 (fused_supported)
   {
     // solar bins (of this shard) whose opacity blocks sit in the first residency round: two blocks per CU
-    static int cus = 0;
-    if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
+    const int cus = device_cus();
     const long first_round_bins = ((long)2 * cus * OP_THREADS) / op.nz;
     fp.sol_early = (int)std::min<long>(ts.n_sol, std::max<long>(0, first_round_bins - (long)(ts.sol_start + ts.sol_lo - op.bin_lo)));
   }
@@ -2420,6 +2440,23 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
     if (op.multi_edge) hipLaunchKernelGGL((k_fused<true, false>), grid, blk, lds, s, op, ts, fp);
     else hipLaunchKernelGGL((k_fused<false, false>), grid, blk, lds, s, op, ts, fp);
   }
+  return true;
+}
+
+bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, hipStream_t s) {
+  if (ts.ng != 8 || slots < 2 || slots > 4 || (ts.nz + 63) / 64 > slots || ts.nzen > MAX_ZEN) return false;
+  OpacityParams op;
+  memset(&op, 0, sizeof(op));
+  op.nz = ts.nz;
+  FusedParams fp;
+  memset(&fp, 0, sizeof(fp));
+  fp.n_op = 0;        // no opacity blocks: the two-stream blocks have nothing to wait for
+  fp.slots = slots;
+  fp.sol_early = ts.n_sol;
+  ts.col_base = 0; ts.accumulate = 1;
+  const int groups = (ts.ng + TSW_COLS - 1) / TSW_COLS;
+  const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)ts.nz + 1);
+  hipLaunchKernelGGL((k_fused<false, false>), dim3((ts.n_sol + ts.n_ir) * groups), dim3(OP_THREADS), lds, s, op, ts, fp);
   return true;
 }
 
@@ -2461,11 +2498,15 @@ __global__ __launch_bounds__(1024) void k_integrate_final(IntegrateParams p) {
   const int nl = p.nz + 1;
   for (int t = threadIdx.x; t < 4 * nl; t += blockDim.x) {
     const int a = t / nl, i = t - a * nl;
-    if (a >= 2 && !p.do_solar) continue;
+    if (a >= 2 && !p.do_solar) {
+      if (p.flux_part) p.flux_n[a * nl + i] = p.flux_part[a * nl + i];  // see k_integrate_one
+      continue;
+    }
     double acc = 0.0;
 #pragma unroll 8
     for (int k = 0; k < p.nchunk; k++) acc = acc + p.partial[((size_t)a * p.nchunk + k) * nl + i];
     p.flux_n[a * nl + i] = acc;
+    if (p.flux_part) p.flux_part[a * nl + i] = acc;
   }
   __syncthreads();
   if (p.f_total)
@@ -2532,10 +2573,16 @@ __global__ __launch_bounds__(INT_LV * INT_CG) void k_integrate_one(IntegratePara
   extern __shared__ __align__(16) double s_int[];  // widths [nchunk*INT_CHUNK], then partial [nchunk][INT_LV]
   const int a = blockIdx.y;
   const bool sol = a >= 2;
-  if (sol && !p.do_solar) return;  // solar rows keep the last solar call's values (clima_radtran.f90:286-289)
   const int nl = p.nz + 1;
   const int lv = threadIdx.x % INT_LV, cg = threadIdx.x / INT_LV;
   const int i = blockIdx.x * INT_LV + lv;
+  if (sol && !p.do_solar) {
+    // solar rows keep the last solar call's values (clima_radtran.f90:286-289).  On a bin-sharded
+    // handle flux_n is the all-reduce buffer and holds REDUCED rows by now: this rank's partial
+    // solar rows are put back from flux_part, or the next reduce would count them `world` times
+    if (p.flux_part && cg == 0 && i < nl) p.flux_n[a * nl + i] = p.flux_part[a * nl + i];
+    return;
+  }
   const double *src = a == 0 ? p.ir_fup_a : a == 1 ? p.ir_fdn_a : a == 2 ? p.sol_fup_a : p.sol_fdn_a;
   const double *freq = sol ? p.sol_freq : p.ir_freq;
   const int lo = sol ? p.sol_lo : p.ir_lo, cnt = sol ? p.sol_n : p.ir_n;
@@ -2570,6 +2617,7 @@ __global__ __launch_bounds__(INT_LV * INT_CG) void k_integrate_one(IntegratePara
     double acc = 0.0;
     for (int k = 0; k < p.nchunk; k++) acc = acc + s_part[k * INT_LV + lv];
     p.flux_n[a * nl + i] = acc;
+    if (p.flux_part) p.flux_part[a * nl + i] = acc;
   }
 }
 

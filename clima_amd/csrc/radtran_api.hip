@@ -156,6 +156,10 @@ struct Radtran {
   hipEvent_t ev_upload = nullptr;   // marks the end of the last column copy out of the pinned staging buffer
   bool upload_pending = false;
   int call_id = 0, checked_id = 0;  // opacity passes enqueued / already checked for device errors
+  // fused hand-off (k_fused): bound of a two-stream block's wait, the last timed-out pass already
+  // handled, the pass of the last solar computation, flags of the last call, re-issued calls so far
+  int fused_max_spins = 400000, checked_timeout = 0, solar_id = 0, fused_fallbacks = 0;
+  bool last_cs = true;
   std::vector<double> last_T, last_P, last_radii;  // host copy for byte accounting
   // opr
   DevBuf<double> d_tau, d_w0, d_g, d_tau_band;
@@ -168,6 +172,7 @@ struct Radtran {
   std::vector<double> f_total;
   bool small_valid = false;
   // sharding
+  DevBuf<double> d_flux_part;  // this rank's partial level rows (d_flux_n is all-reduced in place)
   int shard_rank = 0, shard_world = 1;
   int op_lo = 0, op_n = 0, ir_lo = 0, ir_n = 0, sol_lo = 0, sol_n = 0;
   // stream + profiling
@@ -418,7 +423,7 @@ TwoStreamParams make_twostream_params(Radtran *r, const ColumnDev &col, bool com
   return ts;
 }
 
-void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
+void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool allow_fused = true) {
   r->timer_calls++;
   upload_fields(r);
   const int nz = r->nz;
@@ -463,7 +468,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
         pre_zeroed = true;
       }
     }
-    { KernelTimer t(r, 0); launch_prep(pp, r->stream); t.stop(); }
+    { KernelTimer t(r, 0); launch_prep(pp, r->stream); HIPCHK(hipGetLastError()); t.stop(); }
 
     OpacityParams op;
     std::memset(&op, 0, sizeof(op));
@@ -485,23 +490,28 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     op.stamps = r->d_stamps.p;
 #endif
     op.tau = r->d_tau.p; op.w0 = r->d_w0.p; op.g = r->d_g.p; op.tau_band = r->d_tau_band.p;
-    if (r->fused && pre_zeroed) {
+    if (r->fused && allow_fused && pre_zeroed) {
       TwoStreamParams tsf = make_twostream_params(r, col, compute_solar);
       if (fused_supported(op, tsf)) {
-        FusedParams fp{0, pp.call_id, 400000, r->d_done.p, r->d_err.p, 0, 0};
+        FusedParams fp{0, pp.call_id, r->fused_max_spins, r->d_done.p, r->d_err.p + 1, 0, 0};
         KernelTimer t(r, 1);
         fused_done = launch_fused(op, tsf, fp, r->stream);
+        HIPCHK(hipGetLastError());
         t.stop();
       }
     }
     if (!fused_done) {
       KernelTimer t(r, 1);
-      if (!launch_opacity(op, r->stream))
+      const bool ok = launch_opacity(op, r->stream);
+      HIPCHK(hipGetLastError());
+      if (!ok)
         throw HipFail{"k-distributions with " + std::to_string(r->ng) + " g-points are not supported (1..32)"};
       t.stop();
     }
     r->opr_valid = true;
   }
+  r->last_cs = compute_solar;
+  if (compute_solar) r->solar_id = r->call_id;
 
   TwoStreamParams ts = make_twostream_params(r, col, compute_solar);
   if (!fused_done) {
@@ -510,7 +520,8 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
     const char *mode = getenv("CLIMA_HIP_TS_MODE");
     bool ok = false;
     if (!(mode && std::strcmp(mode, "block") == 0) && ts.nzen <= MAX_ZEN) ok = launch_twostream_w(ts, r->stream, &r->ts_lds, pre_zeroed);
-    if (!ok) ok = launch_twostream(ts, r->stream, &r->ts_lds);
+    if (!ok) { HIPCHK(hipGetLastError()); ok = launch_twostream(ts, r->stream, &r->ts_lds); }
+    HIPCHK(hipGetLastError());
     if (!ok)
       throw HipFail{"nz*ngauss = " + std::to_string(nz * r->ng) + " exceeds what the two-stream kernels can stage"};
     t.stop();
@@ -525,19 +536,25 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity) {
   ip.sol_fup_a = r->wrk_sol.fup_a.p; ip.sol_fdn_a = r->wrk_sol.fdn_a.p;
   ip.ir_freq = r->ir.d_freq.p; ip.sol_freq = r->sol.d_freq.p;
   ip.flux_n = r->flux_override ? r->flux_override : r->d_flux_n.p;
+  ip.flux_part = r->shard_world > 1 ? r->d_flux_part.p : nullptr;
   ip.f_total = r->shard_world == 1 ? (r->ftot_override ? r->ftot_override : r->d_f_total.p) : nullptr;
   ip.nchunk = integrate_chunks(std::max(r->ir_n, r->sol_n));
   ip.partial = r->d_partial.p;
-  { KernelTimer t(r, 3); launch_integrate(ip, r->stream); t.stop(); }
+  { KernelTimer t(r, 3); launch_integrate(ip, r->stream); HIPCHK(hipGetLastError()); t.stop(); }
   r->small_valid = false;
 }
+
+bool recover_fused_timeout(Radtran *r);
 
 void fetch_small(Radtran *r) {
   if (r->small_valid) return;
   const int nl = r->nz + 1;
-  HIPCHK(hipMemcpyAsync(r->h_small, r->d_small.p, sizeof(double) * (5 * nl + 1), hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
-  resolve_events(r);
+  for (int pass = 0; pass < 2; pass++) {
+    HIPCHK(hipMemcpyAsync(r->h_small, r->d_small.p, sizeof(double) * (5 * nl + 1), hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    resolve_events(r);
+    if (r->col_override || !r->column_loaded || !recover_fused_timeout(r)) break;  // re-issued unfused: fetch again
+  }
   // f_total from the four level rows (clima_radtran.f90:287); the one-launch integration leaves it
   // to the host, the other forms computed the same expression on the device
   double *h = r->h_small;
@@ -546,7 +563,7 @@ void fetch_small(Radtran *r) {
 }
 
 bool check_dims(Radtran *r, int dim_T, int dim_P, int d1, int d2, int dim_dz, int has_p, int p1, int p2,
-                const double *pdens, const double *radii, char *err) {
+                int r1, int r2, const double *pdens, const double *radii, char *err) {
   // check_inputs / check_dimensions(_p), clima_radtran.f90:417-491 (same texts)
   if (has_p && ((pdens && !radii) || (radii && !pdens))) { set_err(err, "Both pdensities and radii must be arguments."); return false; }
   if (r->np > 0 && (!has_p || !radii)) { set_err(err, "The model contains particles but \"pdensities\" and \"radii\" are not arguments."); return false; }
@@ -556,6 +573,7 @@ bool check_dims(Radtran *r, int dim_T, int dim_P, int d1, int d2, int dim_dz, in
   if (dim_dz != r->nz) { set_err(err, "\"dz\" has the wrong input dimension."); return false; }
   if (has_p && radii) {
     if (p1 != r->nz || p2 != r->np) { set_err(err, "\"pdensities\" has the wrong input dimension."); return false; }
+    if (r1 != r->nz || r2 != r->np) { set_err(err, "\"radii\" has the wrong input dimension."); return false; }  // :458-461
   }
   return true;
 }
@@ -590,6 +608,26 @@ void do_upload(Radtran *r, double T_surface, const double *T, const double *P, c
   r->last_P.assign(P, P + nz);
   if (r->np > 0 && radii) r->last_radii.assign(radii, radii + (size_t)nz * r->np); else r->last_radii.clear();
   r->column_loaded = true;
+}
+
+// A two-stream block of the fused grid gave up waiting for its bin's opacity blocks (k_fused: the
+// wait is bounded; it can expire when the device is time-sliced with another process, or if blocks
+// were ever dispatched out of index order).  Nothing is wrong with the inputs: the stale parts are
+// computed again through the separate launches.  h_errflag[1] must be current (fetch_small /
+// radtran_synchronize).  Opacities and IR results are stale when the last opacity pass timed out,
+// the solar results when the pass of the last solar computation did.
+bool recover_fused_timeout(Radtran *r) {
+  const int t = r->h_errflag[1];
+  if (t <= r->checked_timeout) return false;
+  r->checked_timeout = r->call_id;
+  const bool stale_opr = t == r->call_id, stale_sol = t == r->solar_id;
+  if (!stale_opr && !stale_sol) return false;
+  if (r->shard_world > 1)  // the partial rows have been all-reduced already: this step cannot be redone here
+    throw HipFail{"The fused opacity/two-stream hand-off timed out on a bin-sharded handle; repeat the step "
+                  "(radtran_fused_set(0) selects the separate launches)."};
+  r->fused_fallbacks++;
+  enqueue_radiate(r, stale_sol || r->last_cs, true, false);
+  return true;
 }
 
 bool surface_device_error(Radtran *r, char *err) {
@@ -912,6 +950,10 @@ void radtran_fused_get(void *ptr, int *enabled) {
   Radtran *r = as_rad(ptr);
   *enabled = (r && r->fused) ? 1 : 0;
 }
+void radtran_fused_fallbacks_get(void *ptr, int *count) {
+  Radtran *r = as_rad(ptr);
+  *count = r ? r->fused_fallbacks : 0;
+}
 
 // clima/fortran/Radtran.f90:109-118
 void radtran_unset_custom_optical_properties(void *ptr) {
@@ -950,6 +992,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   HIPCHK(hipEventCreateWithFlags(&r->ev_upload, hipEventDisableTiming));
   if (const char *f = getenv("CLIMA_HIP_FUSED")) r->fused = atoi(f) != 0;
   if (const char *f = getenv("CLIMA_HIP_BATCH_SHARED")) r->batch_shared = atoi(f) != 0;
+  if (const char *f = getenv("CLIMA_HIP_FUSED_SPINS")) r->fused_max_spins = std::max(0, atoi(f));  // test aid: 0 makes waits expire
 
   // ---- tables to HBM + interpolation slots
   r->slots.clear();
@@ -1038,7 +1081,8 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   mk(r->wrk_sol, 1, r->sol.nw);
   r->d_small.alloc((size_t)5 * (nz + 1) + 1); r->d_small.zero();
   r->d_flux_n.view(r->d_small.p, (size_t)4 * (nz + 1));
-  r->d_err.view(reinterpret_cast<int *>(r->d_small.p + (size_t)5 * (nz + 1)), 1);
+  // two ints share the last double slot: [0] particle-radius clamp, [1] fused hand-off timeout
+  r->d_err.view(reinterpret_cast<int *>(r->d_small.p + (size_t)5 * (nz + 1)), 2);
   r->d_partial.alloc((size_t)4 * integrate_chunks(std::max(r->ir.nw, r->sol.nw)) * (nz + 1)); r->d_partial.zero();
   r->d_f_total.view(r->d_small.p + (size_t)4 * (nz + 1), nz + 1);
   HIPCHK(hipHostMalloc((void **)&r->h_small, sizeof(double) * (5 * (nz + 1) + 1)));
@@ -1109,12 +1153,16 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     TwoStreamParams tb = ts;
     tb.T = r->d_bT.p + (size_t)c0 * nz; tb.T_surface = r->d_bTs.p + c0; tb.b_ncol = nc;
     // shared-matrix batch kernel (ng <= 8); otherwise one full solve per column
-    if (!(r->batch_shared && launch_twostream_ir_batch(tb, nc, r->stream))) {
+    const bool shared_ok = r->batch_shared && launch_twostream_ir_batch(tb, nc, r->stream);
+    HIPCHK(hipGetLastError());
+    if (!shared_ok) {
       if (split) {  // g-point groups add into zeroed spectra
         HIPCHK(hipMemsetAsync(r->d_bup.p, 0, sizeof(double) * spec * nc, r->stream));
         HIPCHK(hipMemsetAsync(r->d_bdn.p, 0, sizeof(double) * spec * nc, r->stream));
       }
-      if (!launch_twostream_w(tb, r->stream, &r->ts_lds, true))
+      const bool ok = launch_twostream_w(tb, r->stream, &r->ts_lds, true);
+      HIPCHK(hipGetLastError());
+      if (!ok)
         throw HipFail{"radiate_ir_batch: nz = " + std::to_string(nz) + " exceeds what the wave two-stream kernel holds (512)"};
     }
     BatchIntegrateParams bp;
@@ -1123,6 +1171,7 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     bp.fup_a = r->d_bup.p; bp.fdn_a = r->d_bdn.p; bp.spec_stride = spec;
     bp.freq = r->ir.d_freq.p; bp.partial = r->d_bpartial.p; bp.flux_n = r->d_flux_n.p; bp.out = r->d_bout.p;
     launch_integrate_batch(bp, nc, r->stream);
+    HIPCHK(hipGetLastError());
   }
   std::vector<double> out((size_t)n * 3 * nl);
   HIPCHK(hipMemcpyAsync(out.data(), r->d_bout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, r->stream));
@@ -1176,25 +1225,33 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
   HIPCHK(hipMemcpyAsync(r->d_cols_arena.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, r->stream));
   r->column_has_particles = r->np > 0;
   const int first_call = r->call_id + 1;
-  for (int c = 0; c < n; c++) {
-    r->col_override = r->d_cols_arena.p + (size_t)c * cc;
-    r->flux_override = r->d_flux_arena.p + (size_t)c * 5 * nl;
-    r->ftot_override = r->flux_override + 4 * nl;
-    try {
-      enqueue_radiate(r, true, true);
-    } catch (...) {
-      r->col_override = r->flux_override = r->ftot_override = nullptr;
-      throw;
-    }
-  }
-  r->col_override = r->flux_override = r->ftot_override = nullptr;
   std::vector<double> out((size_t)n * 5 * nl);
-  HIPCHK(hipMemcpyAsync(out.data(), r->d_flux_arena.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, sizeof(int), hipMemcpyDeviceToHost, r->stream));
-  // the handle's own level fluxes = the last column's
-  HIPCHK(hipMemcpyAsync(r->d_flux_n.p, r->d_flux_arena.p + (size_t)(n - 1) * 5 * nl, sizeof(double) * 4 * nl, hipMemcpyDeviceToDevice, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
-  resolve_events(r);
+  auto run_all = [&](bool allow_fused) {
+    for (int c = 0; c < n; c++) {
+      r->col_override = r->d_cols_arena.p + (size_t)c * cc;
+      r->flux_override = r->d_flux_arena.p + (size_t)c * 5 * nl;
+      r->ftot_override = r->flux_override + 4 * nl;
+      try {
+        enqueue_radiate(r, true, true, allow_fused);
+      } catch (...) {
+        r->col_override = r->flux_override = r->ftot_override = nullptr;
+        throw;
+      }
+    }
+    r->col_override = r->flux_override = r->ftot_override = nullptr;
+    HIPCHK(hipMemcpyAsync(out.data(), r->d_flux_arena.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, r->stream));
+    // the handle's own level fluxes = the last column's
+    HIPCHK(hipMemcpyAsync(r->d_flux_n.p, r->d_flux_arena.p + (size_t)(n - 1) * 5 * nl, sizeof(double) * 4 * nl, hipMemcpyDeviceToDevice, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    resolve_events(r);
+  };
+  run_all(true);
+  if (r->h_errflag[1] >= first_call) {  // a fused hand-off wait expired in some column: the batch again, unfused
+    r->fused_fallbacks++;
+    run_all(false);
+  }
+  r->checked_timeout = r->call_id;
   r->small_valid = false;
   r->column_loaded = false;   // d_col does not hold the last column: a resident call needs an upload first
   if (*r->h_errflag >= first_call) {
@@ -1218,9 +1275,12 @@ void radtran_synchronize(void *ptr, char *err) {
   GUARD(r, ptr, err);
   if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
   TRY
-  HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, sizeof(int), hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
-  resolve_events(r);
+  for (int pass = 0; pass < 2; pass++) {
+    HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    resolve_events(r);
+    if (!r->column_loaded || !recover_fused_timeout(r)) break;
+  }
   surface_device_error(r, err);
   CATCH(err)
 }
@@ -1229,14 +1289,14 @@ void radtran_radiate_wrapper(void *ptr, const double *T_surface, const int *dim_
                              const int *dim_P, const double *P, const int *dim1_d, const int *dim2_d,
                              const double *densities, const int *dim_dz, const double *dz,
                              const int *has_particles, const int *dim1_p, const int *dim2_p,
-                             const double *pdensities, const double *radii, const int *compute_solar,
-                             const int *compute_opacity, char *err) {
+                             const double *pdensities, const int *dim1_r, const int *dim2_r, const double *radii,
+                             const int *compute_solar, const int *compute_opacity, char *err) {
   clear_err(err);
   GUARD(r, ptr, err);
   if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
   const int hp = has_particles ? *has_particles : 0;
   if (!check_dims(r, *dim_T, *dim_P, *dim1_d, *dim2_d, *dim_dz, hp, dim1_p ? *dim1_p : 0, dim2_p ? *dim2_p : 0,
-                  hp ? pdensities : nullptr, hp ? radii : nullptr, err))
+                  dim1_r ? *dim1_r : 0, dim2_r ? *dim2_r : 0, hp ? pdensities : nullptr, hp ? radii : nullptr, err))
     return;
   TRY
   do_upload(r, *T_surface, T, P, densities, dz, hp ? pdensities : nullptr, hp ? radii : nullptr);
@@ -1252,10 +1312,12 @@ void radtran_toa_fluxes_wrapper(void *ptr, const double *T_surface, const int *d
                                 const int *dim_P, const double *P, const int *dim1_d, const int *dim2_d,
                                 const double *densities, const int *dim_dz, const double *dz,
                                 const int *has_particles, const int *dim1_p, const int *dim2_p,
-                                const double *pdensities, const double *radii, const int *compute_solar,
-                                const int *compute_opacity, double *ISR, double *OLR, char *err) {
+                                const double *pdensities, const int *dim1_r, const int *dim2_r, const double *radii,
+                                const int *compute_solar, const int *compute_opacity, double *ISR, double *OLR,
+                                char *err) {
   radtran_radiate_wrapper(ptr, T_surface, dim_T, T, dim_P, P, dim1_d, dim2_d, densities, dim_dz, dz,
-                          has_particles, dim1_p, dim2_p, pdensities, radii, compute_solar, compute_opacity, err);
+                          has_particles, dim1_p, dim2_p, pdensities, dim1_r, dim2_r, radii, compute_solar,
+                          compute_opacity, err);
   if (err && err[0]) return;
   Radtran *r = as_rad(ptr);
   if (!r) return;
@@ -1299,6 +1361,10 @@ void radtran_set_bin_shard(void *ptr, const int *rank, const int *world, char *e
   // bins outside the shard hold zeros so that sharded per-bin spectra add up across ranks
   for (WrkObj *w : {&r->wrk_ir, &r->wrk_sol}) { w->fup_a.zero(r->stream); w->fdn_a.zero(r->stream); w->amean.zero(r->stream); w->tau_band.zero(r->stream); }
   r->d_flux_n.zero(r->stream);
+  if (*world > 1) {
+    if (r->d_flux_part.n < (size_t)4 * (r->nz + 1)) r->d_flux_part.alloc((size_t)4 * (r->nz + 1));
+    r->d_flux_part.zero(r->stream);
+  }
   HIPCHK(hipStreamSynchronize(r->stream));
   CATCH(err)
 }
@@ -1456,6 +1522,75 @@ void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, d
   CATCH(err)
 }
 
+
+// Test hook: ONE column through the production two-stream kernels with its optical properties
+// and Planck values given directly -- the inputs and outputs of the reference's two_stream_ir /
+// two_stream_solar (src/radtran/clima_radtran_twostream.f90:10-295), which is what
+// tests/golden/twostream_golden.npz holds.  The column is presented as one bin that lies in both
+// channels, `ng` g-points carrying the same tau/w0 with weights wbin (sum 1), one zenith angle u0 of
+// weight 1, unit stellar flux and unit factors, so the kernels' weighted sums reproduce the solver's
+// own outputs.  form: 0 wave-per-column kernel (k_twostream_w<slots>), 1 workgroup-per-bin kernel
+// (k_twostream), 2 the two-stream part of the fused grid (k_fused, slots 2..4, ng = 8),
+// 3 batched shared-opacity IR kernel (k_twostream_ir_batch<slots>, IR outputs only).
+// slots = layer slots per lane (>= ceil(nz/64)).  Outputs are TOA-first like the solver's.
+void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, const int *slots, const double *tau,
+                           const double *w0, const double *g, const double *bplanck, const double *ir_par,
+                           const double *sol_par, const double *wbin, double *ir_fup, double *ir_fdn,
+                           double *sol_fup, double *sol_fdn, double *sol_amean, char *err) {
+  clear_err(err);
+  TRY
+  const int nz = *nz_, ng = *ng_, nl = nz + 1;
+  if (nz < 1 || ng < 1 || ng > 32) throw HipFail{"clima_test_two_stream: bad nz / ng"};
+  std::vector<double> h_tau((size_t)ng * nz), h_w0((size_t)ng * nz);
+  for (int c = 0; c < ng; c++)
+    for (int i = 0; i < nz; i++) { h_tau[(size_t)c * nz + i] = tau[i]; h_w0[(size_t)c * nz + i] = w0[i]; }
+  DevBuf<double> d_tau, d_w0, d_g, d_tb, d_bp, d_wbin, d_freq, d_T, d_one, d_em, d_alb, d_zu, d_zw, d_ziu, d_out;
+  d_tau.upload(h_tau); d_w0.upload(h_w0);
+  d_g.upload(std::vector<double>(g, g + nz));
+  d_tb.upload(std::vector<double>(nz, 0.0));
+  d_bp.upload(std::vector<double>(bplanck, bplanck + nl));
+  d_wbin.upload(std::vector<double>(wbin, wbin + ng));
+  d_freq.upload(std::vector<double>{2.0e13, 1.0e13});
+  d_T.upload(std::vector<double>(nl, 250.0));
+  d_one.upload(std::vector<double>{1.0});
+  d_em.upload(std::vector<double>{ir_par[0]});
+  d_alb.upload(std::vector<double>{sol_par[1]});
+  d_zu.upload(std::vector<double>{sol_par[0]});
+  d_zw.upload(std::vector<double>{1.0});
+  d_ziu.upload(std::vector<double>{1.0 / sol_par[0]});
+  d_out.alloc((size_t)7 * nl); d_out.zero();
+  TwoStreamParams ts;
+  std::memset(&ts, 0, sizeof(ts));
+  ts.nz = nz; ts.ng = ng;
+  ts.n_sol = (*form == 3) ? 0 : 1; ts.n_ir = 1;
+  ts.tau = d_tau.p; ts.w0 = d_w0.p; ts.g = d_g.p; ts.tau_band = d_tb.p;
+  ts.wbin = d_wbin.p; ts.freq = d_freq.p;
+  ts.bplanck = d_bp.p; ts.force_slots = *slots;
+  ts.T = d_T.p; ts.T_surface = d_T.p;
+  ts.emissivity = d_em.p; ts.has_hard_surface = ir_par[1] != 0.0 ? 1 : 0; ts.ir_tau_min = ir_par[2];
+  ts.nzen = 1; ts.zen_u = d_zu.p; ts.zen_w = d_zw.p; ts.zen_iu = d_ziu.p;
+  ts.zen_u_v[0] = sol_par[0]; ts.zen_w_v[0] = 1.0; ts.zen_iu_v[0] = 1.0 / sol_par[0];
+  ts.albedo = d_alb.p; ts.photons_sol = d_one.p; ts.photon_scale_factor = 1.0; ts.diurnal_fac = 1.0;
+  ts.am_f1 = d_one.p; ts.am_f2 = d_one.p; ts.am_dw = d_one.p;
+  ts.ir_fup_a = d_out.p; ts.ir_fdn_a = d_out.p + nl; ts.sol_fup_a = d_out.p + 2 * nl; ts.sol_fdn_a = d_out.p + 3 * nl;
+  ts.sol_amean = d_out.p + 4 * nl; ts.ir_tau_band = d_out.p + 5 * nl; ts.sol_tau_band = d_out.p + 6 * nl;
+  bool ok = false;
+  size_t lds = 0;
+  if (*form == 0) ok = launch_twostream_w(ts, nullptr, &lds, false);
+  else if (*form == 1) ok = launch_twostream(ts, nullptr, &lds);
+  else if (*form == 2) ok = launch_fused_twostream_only(ts, *slots, nullptr);
+  else if (*form == 3) { ts.b_T = 0; ts.b_Ts = 0; ts.b_out = 0; ok = launch_twostream_ir_batch(ts, 1, nullptr); }
+  HIPCHK(hipGetLastError());
+  if (!ok) throw HipFail{"clima_test_two_stream: this form does not cover the requested shape"};
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<double> out((size_t)5 * nl);
+  HIPCHK(hipMemcpy(out.data(), d_out.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
+  double *dst[5] = {ir_fup, ir_fdn, sol_fup, sol_fdn, sol_amean};
+  for (int a = 0; a < 5; a++)
+    for (int n = 0; n < nl; n++) dst[a][n] = out[(size_t)a * nl + (nz - n)];  // the kernels store ground-first (radiate.f90:140-154)
+  CATCH(err)
+}
+
 // ---- reference-named getters / setters (clima/fortran/Radtran.f90) -------------------
 
 static double bolometric(Radtran *r) {  // Radtran_bolometric_flux, clima_radtran.f90:353-364
@@ -1516,8 +1651,14 @@ void radtran_zenith_weights_set(void *ptr, const int *dim1, const double *arr) {
   for (int i = 0; i < *dim1 && i < (int)r->zenith_w.size(); i++) r->zenith_w[i] = arr[i];
   r->fields_dirty = true;
 }
-void radtran_has_hard_surface_get(void *ptr, int *val) { Radtran *r = as_rad(ptr); if (r) *val = r->has_hard_surface ? 1 : 0; }
-void radtran_has_hard_surface_set(void *ptr, const int *val) { Radtran *r = as_rad(ptr); if (r) r->has_hard_surface = (*val != 0); }
+// logical(c_bool) in the reference (clima/fortran/Radtran.f90:211-227; Radtran_pxd.pxd:45-46 binds bool*):
+// exactly one byte is read or written
+static_assert(sizeof(bool) == 1, "logical(c_bool) is one byte");
+void radtran_has_hard_surface_get(void *ptr, bool *val) { Radtran *r = as_rad(ptr); if (r) *val = r->has_hard_surface; }
+void radtran_has_hard_surface_set(void *ptr, const bool *val) {
+  Radtran *r = as_rad(ptr);
+  if (r) r->has_hard_surface = (*reinterpret_cast<const unsigned char *>(val) != 0);
+}
 void radtran_photon_scale_factor_get(void *ptr, double *val) { Radtran *r = as_rad(ptr); if (r) *val = r->photon_scale_factor; }
 void radtran_photon_scale_factor_set(void *ptr, const double *val) { Radtran *r = as_rad(ptr); if (r) r->photon_scale_factor = *val; }
 void radtran_ir_tau_min_get(void *ptr, double *val) { Radtran *r = as_rad(ptr); if (r) *val = r->ir_tau_min; }

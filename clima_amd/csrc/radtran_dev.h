@@ -141,6 +141,10 @@ struct TwoStreamParams {
   const double *tau, *w0, *g, *tau_band;   // opr
   const double *wbin;
   const double *freq;                      // opacity grid [nw+1]
+  // test hook (clima_test_two_stream): Planck values at the levels given directly [nz+1] TOA-first
+  // instead of computed from T (null in production), and a slot count above ceil(nz/64) (0: none)
+  const double *bplanck;
+  int force_slots;
   // IR
   const double *T, *T_surface;
   const double *emissivity;                // [nw_ir]
@@ -166,7 +170,7 @@ struct FusedParams {
   int call_id;     // value an opacity block publishes in done[block] when its results are out
   int max_spins;   // bound of a two-stream block's wait
   int *done;       // [n_op]
-  int *err_flag;
+  int *timeout_flag;  // id of the last call in which a two-stream block's wait expired
   int slots;       // layers per lane of the two-stream part: ceil(nz/64) = 2..4 (launcher)
   int sol_early;   // solar bins whose opacities the first round of opacity blocks produces (launcher)
 };
@@ -179,6 +183,7 @@ struct IntegrateParams {
   const double *ir_fup_a, *ir_fdn_a, *sol_fup_a, *sol_fdn_a;
   const double *ir_freq, *sol_freq;        // channel freq [nw_ch+1]
   double *flux_n;                          // [4][nz+1]
+  double *flux_part;                       // bin-sharded handles: this rank's partial rows (flux_n is all-reduced in place); else null
   double *f_total;
   double *partial;                         // [4][nchunk][nz+1] chunk sums
   int nchunk;
@@ -204,6 +209,8 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
 bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s);
 bool fused_supported(const OpacityParams &op, const TwoStreamParams &ts);
 bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s);
+// test hook: the two-stream blocks of the fused grid alone (no opacity blocks), on opacities already in HBM
+bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, hipStream_t s);
 int twostream_w_groups(int ng);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
 void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t s);

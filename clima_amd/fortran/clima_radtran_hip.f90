@@ -139,11 +139,11 @@ module clima_radtran_hip
       character(c_char), intent(out) :: err(*)
     end subroutine
     subroutine c_radtran_radiate_wrapper(ptr, T_surface, dim_T, T, dim_P, P, dim1_d, dim2_d, densities, &
-                                       dim_dz, dz, has_particles, dim1_p, dim2_p, pdensities, radii, &
+                                       dim_dz, dz, has_particles, dim1_p, dim2_p, pdensities, dim1_r, dim2_r, radii, &
                                        compute_solar, compute_opacity, err) bind(c, name="radtran_radiate_wrapper")
       import; type(c_ptr), value :: ptr
       real(c_double), intent(in) :: T_surface
-      integer(c_int), intent(in) :: dim_T, dim_P, dim1_d, dim2_d, dim_dz, has_particles, dim1_p, dim2_p
+      integer(c_int), intent(in) :: dim_T, dim_P, dim1_d, dim2_d, dim_dz, has_particles, dim1_p, dim2_p, dim1_r, dim2_r
       real(c_double), intent(in) :: T(*), P(*), densities(*), dz(*), pdensities(*), radii(*)
       integer(c_int), intent(in) :: compute_solar, compute_opacity
       character(c_char), intent(out) :: err(*)
@@ -245,7 +245,7 @@ module clima_radtran_hip
     end subroutine
     subroutine c_radtran_has_hard_surface_set(ptr, val) bind(c, name="radtran_has_hard_surface_set")
       import; type(c_ptr), value :: ptr
-      integer(c_int), intent(in) :: val
+      logical(c_bool), intent(in) :: val  ! as clima/fortran/Radtran.f90:220-227
     end subroutine
     subroutine c_radtran_photon_scale_factor_set(ptr, val) bind(c, name="radtran_photon_scale_factor_set")
       import; type(c_ptr), value :: ptr
@@ -488,13 +488,12 @@ contains
   !> the public fields are read on every radiate (clima_radtran.f90:262-313)
   subroutine push_fields(self)
     class(Radtran), intent(inout) :: self
-    integer(c_int) :: hs
+    logical(c_bool) :: hs
     call c_radtran_zenith_u_set(self%handle, size(self%zenith_u), self%zenith_u)
     call c_radtran_zenith_weights_set(self%handle, size(self%zenith_weights), self%zenith_weights)
     call c_radtran_surface_albedo_set(self%handle, size(self%surface_albedo), self%surface_albedo)
     call c_radtran_surface_emissivity_set(self%handle, size(self%surface_emissivity), self%surface_emissivity)
-    hs = 0
-    if (self%has_hard_surface) hs = 1
+    hs = self%has_hard_surface
     call c_radtran_has_hard_surface_set(self%handle, hs)
     call c_radtran_photon_scale_factor_set(self%handle, self%photon_scale_factor)
     call c_radtran_ir_tau_min_set(self%handle, self%ir_tau_min)
@@ -557,18 +556,16 @@ contains
     call push_fields(self)
     dummy = 0.0_dp
     if (present(radii)) then
+      ! both shapes go across: check_dimensions_p (clima_radtran.f90:446-463) reports them separately,
+      ! after the T / P / densities / dz checks
       hp = 1; p1 = size(pdensities,1); p2 = size(pdensities,2)
-      if (size(radii,1) /= p1 .or. size(radii,2) /= p2) then
-        err = '"radii" has the wrong input dimension.'
-        return
-      endif
       call c_radtran_radiate_wrapper(self%handle, T_surface, size(T), T, size(P), P, size(densities,1), &
-                                   size(densities,2), densities, size(dz), dz, hp, p1, p2, pdensities, radii, &
-                                   cs, co, err_c)
+                                   size(densities,2), densities, size(dz), dz, hp, p1, p2, pdensities, &
+                                   size(radii,1), size(radii,2), radii, cs, co, err_c)
     else
       hp = 0; p1 = 0; p2 = 0
       call c_radtran_radiate_wrapper(self%handle, T_surface, size(T), T, size(P), P, size(densities,1), &
-                                   size(densities,2), densities, size(dz), dz, hp, p1, p2, dummy, dummy, &
+                                   size(densities,2), densities, size(dz), dz, hp, p1, p2, dummy, p1, p2, dummy, &
                                    cs, co, err_c)
     endif
     call take_err(err_c, err)

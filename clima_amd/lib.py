@@ -12,6 +12,7 @@ ERR_LEN = 1024
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
+_bp = C.POINTER(C.c_bool)
 _vp = C.c_void_p
 _vpp = C.POINTER(C.c_void_p)
 _err = C.c_char_p
@@ -28,10 +29,10 @@ SIGNATURES = {
     "radtran_set_channels": [_vp, _ip, _dp, _ip, _dp, _err],
     "radtran_set_photons_sol": [_vp, _ip, _dp, _err],
     "radtran_create_end": [_vp, _ip, _dp, _err],
-    "radtran_radiate_wrapper": [_vp, _dp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _dp,
-                                _ip, _ip, _err],
-    "radtran_toa_fluxes_wrapper": [_vp, _dp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _dp,
-                                   _ip, _ip, _dp, _dp, _err],
+    "radtran_radiate_wrapper": [_vp, _dp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _ip, _ip,
+                                _dp, _ip, _ip, _err],
+    "radtran_toa_fluxes_wrapper": [_vp, _dp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _ip, _ip,
+                                   _dp, _ip, _ip, _dp, _dp, _err],
     "radtran_apply_radiation_enhancement": [_vp, _dp],
     "radtran_set_custom_optical_properties": [_vp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, _err],
     "radtran_unset_custom_optical_properties": [_vp],
@@ -41,6 +42,7 @@ SIGNATURES = {
     "radtran_set_opacity_labels": [_vp, _err, _err, _err, _err],
     "radtran_fused_set": [_vp, _ip],
     "radtran_fused_get": [_vp, _ip],
+    "radtran_fused_fallbacks_get": [_vp, _ip],
     "radtran_toa_fluxes_batch": [_vp, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _err],
     "radtran_radiate_ir_batch": [_vp, _ip, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _err],
     "radtran_upload_column": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],
@@ -60,6 +62,7 @@ SIGNATURES = {
     "clima_test_device_exp": [_ip, _dp, _dp, _err],
     "clima_test_device_rcp": [_ip, _dp, _dp, _err],
     "clima_test_wave_scan": [_ip, _dp, _dp, _dp, _err],
+    "clima_test_two_stream": [_ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],
     "radtran_set_bolometric_flux_wrapper": [_vp, _dp],
     "radtran_bolometric_flux_wrapper": [_vp, _dp],
     "radtran_skin_temperature_wrapper": [_vp, _dp, _dp],
@@ -75,8 +78,8 @@ SIGNATURES = {
     "radtran_surface_emissivity_get_size": [_vp, _ip],
     "radtran_surface_emissivity_get": [_vp, _ip, _dp],
     "radtran_surface_emissivity_set": [_vp, _ip, _dp],
-    "radtran_has_hard_surface_get": [_vp, _ip],
-    "radtran_has_hard_surface_set": [_vp, _ip],
+    "radtran_has_hard_surface_get": [_vp, _bp],
+    "radtran_has_hard_surface_set": [_vp, _bp],
     "radtran_photon_scale_factor_get": [_vp, _dp],
     "radtran_photon_scale_factor_set": [_vp, _dp],
     "radtran_ir_tau_min_get": [_vp, _dp],

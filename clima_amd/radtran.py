@@ -184,16 +184,15 @@ class Radtran:
             raise ClimaException("Both pdensities and radii must be arguments.")
         if has_p:
             pdensities, radii = _fo(pdensities), _fo(radii)
-            if pdensities.shape != radii.shape:
-                raise ClimaException('"radii" has the wrong input dimension.')
             p1, p2 = pdensities.shape if pdensities.ndim == 2 else (pdensities.shape[0], 1)
+            r1, r2 = radii.shape if radii.ndim == 2 else (radii.shape[0], 1)
             pd, ra = _d(pdensities), _d(radii)
         else:
-            p1 = p2 = 0
+            p1 = p2 = r1 = r2 = 0
             pd = ra = None
         keep = (T, P, dz, densities, pdensities, radii)
         args = (_i(len(T)), _d(T), _i(len(P)), _d(P), _i(densities.shape[0]), _i(densities.shape[1]), _d(densities),
-                _i(len(dz)), _d(dz), _i(1 if has_p else 0), _i(p1), _i(p2), pd, ra)
+                _i(len(dz)), _d(dz), _i(1 if has_p else 0), _i(p1), _i(p2), pd, _i(r1), _i(r2), ra)
         return keep, args
 
     def radiate(self, T_surface, T, P, densities, dz, pdensities=None, radii=None, compute_solar=True,
@@ -335,6 +334,13 @@ class Radtran:
     def fused(self, on):
         self._L.radtran_fused_set(self._ptr, _i(1 if on else 0))
 
+    @property
+    def fused_fallbacks(self):
+        """Calls re-issued through the separate launches after a fused hand-off wait expired."""
+        v = C.c_int()
+        self._L.radtran_fused_fallbacks_get(self._ptr, C.byref(v))
+        return v.value
+
     def flux_tensor(self):
         """The packed level fluxes [ir_up, ir_dn, sol_up, sol_dn][nz+1] as a torch CUDA tensor
         aliasing the library's buffer (the RCCL all-reduce payload of a bin-sharded run)."""
@@ -445,14 +451,14 @@ class Radtran:
         def get(self):
             v = ctype()
             getattr(self._L, "radtran_%s_get" % name)(self._ptr, C.byref(v))
-            return bool(v.value) if ctype is C.c_int else v.value
+            return bool(v.value) if ctype is C.c_bool else v.value
 
         def set_(self, val):
-            getattr(self._L, "radtran_%s_set" % name)(self._ptr, C.byref(ctype(int(val) if ctype is C.c_int else float(val))))
+            getattr(self._L, "radtran_%s_set" % name)(self._ptr, C.byref(ctype(bool(val) if ctype is C.c_bool else float(val))))
 
         return property(get, set_)
 
-    has_hard_surface = _scalar("has_hard_surface", C.c_int)
+    has_hard_surface = _scalar("has_hard_surface", C.c_bool)  # logical(c_bool), clima/cython/Radtran_pxd.pxd:45-46
     photon_scale_factor = _scalar("photon_scale_factor", C.c_double)
     ir_tau_min = _scalar("ir_tau_min", C.c_double)
     diurnal_fac = _scalar("diurnal_fac", C.c_double)

@@ -16,6 +16,10 @@
 #ifndef CLIMA_RADTRAN_HIP_H
 #define CLIMA_RADTRAN_HIP_H
 
+#ifndef __cplusplus
+#include <stdbool.h>  /* logical(c_bool) <-> bool (1 byte), clima/fortran/Radtran.f90:211-227 */
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -79,14 +83,16 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
  * ---------------------------------------------------------------------------------- */
 
 /* Radtran%radiate (clima_radtran.f90:221-318).  densities(dim1_d,dim2_d),
- * pdensities/radii(dim1_p,dim2_p) column-major; pass has_particles=0 and NULLs when the
- * optional arguments are absent.  Dimension errors reproduce check_inputs (:417-491). */
+ * pdensities(dim1_p,dim2_p), radii(dim1_r,dim2_r) column-major; pass has_particles=0 and NULLs
+ * when the optional arguments are absent.  Dimension errors reproduce check_inputs (:417-491),
+ * including the separate `"radii" has the wrong input dimension.` of check_dimensions_p (:459). */
 void radtran_radiate_wrapper(void *ptr, const double *T_surface, const int *dim_T,
                              const double *T, const int *dim_P, const double *P,
                              const int *dim1_d, const int *dim2_d, const double *densities,
                              const int *dim_dz, const double *dz, const int *has_particles,
                              const int *dim1_p, const int *dim2_p, const double *pdensities,
-                             const double *radii, const int *compute_solar,
+                             const int *dim1_r, const int *dim2_r, const double *radii,
+                             const int *compute_solar,
                              const int *compute_opacity, char *err);
 /* Radtran%TOA_fluxes (clima_radtran.f90:320-342) */
 void radtran_toa_fluxes_wrapper(void *ptr, const double *T_surface, const int *dim_T,
@@ -94,7 +100,8 @@ void radtran_toa_fluxes_wrapper(void *ptr, const double *T_surface, const int *d
                                 const int *dim1_d, const int *dim2_d, const double *densities,
                                 const int *dim_dz, const double *dz, const int *has_particles,
                                 const int *dim1_p, const int *dim2_p, const double *pdensities,
-                                const double *radii, const int *compute_solar,
+                                const int *dim1_r, const int *dim2_r, const double *radii,
+                                const int *compute_solar,
                                 const int *compute_opacity, double *ISR, double *OLR,
                                 char *err);
 /* Radtran%apply_radiation_enhancement (clima_radtran.f90:402-411) */
@@ -167,6 +174,11 @@ void radtran_set_opacity_labels(void *ptr, const char *k_method, const char *wat
  * 0 = one launch per kernel.  Same results to rounding; CLIMA_HIP_FUSED=0 sets the default off. */
 void radtran_fused_set(void *ptr, const int *enable);
 void radtran_fused_get(void *ptr, int *enabled);
+/* A two-stream block of the fused grid waits (bounded) for the opacity blocks of its bin.  If that
+ * wait ever expires the call is NOT failed: the library computes it again through the separate
+ * launches before results are handed out.  This counts such re-issues on the handle (0 in normal
+ * operation; CLIMA_HIP_FUSED_SPINS=0 forces them, for tests). */
+void radtran_fused_fallbacks_get(void *ptr, int *count);
 /* HIP stream the handle launches on (for callers that order other work against it) */
 void radtran_stream_get(void *ptr, void **stream);
 /* per-kernel device time (HIP events on the handle's stream).  enable = 1 records events
@@ -193,6 +205,17 @@ void clima_test_device_rcp(const int *n, const double *x, double *y, char *err);
  * affine inclusive scan, the same through build+apply, shift up by one lane, lane reversal) */
 void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, double *out, char *err);
 
+/* test hook: one column through the PRODUCTION two-stream kernels with tau, w0, g (nz, TOA-first) and
+ * the Planck values of the levels (nz+1) given directly -- the arguments of the reference's
+ * two_stream_ir / two_stream_solar (src/radtran/clima_radtran_twostream.f90:10-295).  ir_par =
+ * {emissivity, has_hard_surface, ir_tau_min}, sol_par = {u0, Rsfc}; ng g-points of weights wbin (sum
+ * 1) carry the same column.  form 0: k_twostream_w<slots>, 1: k_twostream, 2: two-stream part of
+ * k_fused (slots 2..4, ng 8), 3: k_twostream_ir_batch<slots> (IR only).  Outputs (nz+1) TOA-first. */
+void clima_test_two_stream(const int *nz, const int *ng, const int *form, const int *slots, const double *tau,
+                           const double *w0, const double *g, const double *bplanck, const double *ir_par,
+                           const double *sol_par, const double *wbin, double *ir_fup, double *ir_fdn,
+                           double *sol_fup, double *sol_fdn, double *sol_amean, char *err);
+
 /* OpticalPropertiesResult (clima_radtran_types.f90:242-247), for parity checks:
  * tau,w0 (nz,ngauss,nw) and g,tau_band (nz,nw), column-major, TOA-first. */
 void radtran_opr_get(void *ptr, double *tau, double *w0, double *g, double *tau_band, char *err);
@@ -216,8 +239,8 @@ void radtran_surface_albedo_set(void *ptr, const int *dim1, const double *arr); 
 void radtran_surface_emissivity_get_size(void *ptr, int *dim1);                      /* :182 */
 void radtran_surface_emissivity_get(void *ptr, const int *dim1, double *arr);        /* :191 */
 void radtran_surface_emissivity_set(void *ptr, const int *dim1, const double *arr);  /* :201 */
-void radtran_has_hard_surface_get(void *ptr, int *val);                              /* :211 */
-void radtran_has_hard_surface_set(void *ptr, const int *val);                        /* :220 */
+void radtran_has_hard_surface_get(void *ptr, bool *val);                             /* :211, logical(c_bool) */
+void radtran_has_hard_surface_set(void *ptr, const bool *val);                       /* :220, logical(c_bool) */
 void radtran_photon_scale_factor_get(void *ptr, double *val);                        /* :229 */
 void radtran_photon_scale_factor_set(void *ptr, const double *val);                  /* :238 */
 void radtran_ir_tau_min_get(void *ptr, double *val);                                 /* :247 */

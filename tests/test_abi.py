@@ -59,6 +59,37 @@ def test_handle_lifecycle_and_argument_validation(hip_lib):
     assert b"invalid Radtran handle" in err.value
 
 
+def test_has_hard_surface_is_a_one_byte_bool(hip_lib):
+    """`logical(c_bool)` / `bool*` in the reference (clima/fortran/Radtran.f90:211-227,
+    clima/cython/Radtran_pxd.pxd:45-46: Radtran.pyx passes the address of a 1-byte local).  The getter
+    must write exactly one byte, the setter read exactly one: the slot sits between guard bytes."""
+    L = hip_lib
+    h = C.c_void_p()
+    L.allocate_radtran(C.byref(h))
+    buf = (C.c_ubyte * 9)(*([0xAB] * 9))
+    slot = C.cast(C.byref(buf, 4), C.POINTER(C.c_bool))
+    L.radtran_has_hard_surface_get(h, slot)              # default .true. (clima_radtran.f90:60)
+    assert list(buf) == [0xAB] * 4 + [1] + [0xAB] * 4
+    buf[4] = 0                                            # False next to non-zero neighbours
+    L.radtran_has_hard_surface_set(h, slot)
+    out = (C.c_ubyte * 9)(*([0xCD] * 9))
+    L.radtran_has_hard_surface_get(h, C.cast(C.byref(out, 4), C.POINTER(C.c_bool)))
+    assert list(out) == [0xCD] * 4 + [0] + [0xCD] * 4    # 4 bytes read as an int would have said True
+    buf[4] = 1
+    L.radtran_has_hard_surface_set(h, slot)
+    L.radtran_has_hard_surface_get(h, C.cast(C.byref(out, 4), C.POINTER(C.c_bool)))
+    assert list(out) == [0xCD] * 4 + [1] + [0xCD] * 4
+    L.deallocate_radtran(h)
+
+
+def test_header_declares_bool_for_has_hard_surface():
+    text = open(os.path.join(ROOT, "include", "clima_radtran_hip.h")).read()
+    assert "radtran_has_hard_surface_get(void *ptr, bool *val)" in text
+    assert "radtran_has_hard_surface_set(void *ptr, const bool *val)" in text
+    from clima_amd import lib
+    assert lib.SIGNATURES["radtran_has_hard_surface_get"][1] is C.POINTER(C.c_bool)
+
+
 def test_no_cpu_fallback_in_product():
     """The product path must not reach into oracle/ (parity claims depend on it)."""
     pkg = os.path.join(ROOT, "clima_amd")

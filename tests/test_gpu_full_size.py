@@ -103,6 +103,47 @@ def test_bin_sharded_partials_add_up(nominal):
     assert np.allclose(acc, full, rtol=1e-12, atol=1e-9)
 
 
+def test_bin_sharded_ir_only_step_does_not_recount_solar(small_tables):
+    """The RCE-Jacobian pattern on a bin-sharded handle: a full step, then `compute_solar=False`
+    steps (clima_radtran.f90:286-289 keeps the last solar results).  The level-flux buffer is
+    all-reduced IN PLACE, so after a step it holds reduced rows; an IR-only step must put this rank's
+    PARTIAL solar rows back before the next reduce, or they are counted `world` times.  World 2 is
+    emulated on one GPU: two sharded handles, the 'all-reduce' is their sum written into both."""
+    import torch
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    tb = small_tables
+    nz = 60
+    col = S.modern_earth_column(nz)
+    col2 = S.perturbed_columns(1, nz, seed=3)[0]
+    ranks = [Radtran(tb, nz, 3, 0.2) for _ in range(2)]
+    whole = Radtran(tb, nz, 3, 0.2)
+    for k, r in enumerate(ranks):
+        r.set_bin_shard(k, 2)
+    flux = [r.flux_tensor() for r in ranks]
+
+    def step(c, **kw):
+        for r in ranks:
+            r.upload_column(*c.args())
+            r.radiate_resident(**kw)
+            r.synchronize()
+        total = flux[0] + flux[1]
+        torch.cuda.synchronize()
+        for f, r in zip(flux, ranks):
+            f.copy_(total)
+            torch.cuda.synchronize()
+            r.finish_reduced()
+        whole.radiate(*c.args(), **kw)
+        for r in ranks:
+            np.testing.assert_allclose(np.array(r.f_total), np.array(whole.f_total), rtol=1e-12, atol=1e-9)
+            np.testing.assert_allclose(r.wrk_sol.fdn_n, whole.wrk_sol.fdn_n, rtol=1e-12, atol=1e-9)
+
+    step(col)
+    step(col2, compute_solar=False)
+    step(col, compute_solar=False, compute_opacity=False)
+    step(col2)
+
+
 def test_separate_launch_form_at_full_size(nominal):
     """config 2 with one launch per kernel (the form the fused grid replaces) gives the same TOA
     fluxes to rounding."""
@@ -180,3 +221,39 @@ def test_config5_500_layers_full_size(O):
     shards; test_bin_sharded_partials_add_up covers the sharding itself)."""
     from clima_amd import synthetic as S
     _full_size_against_oracle(O, S.modern_earth_tables(), 500, 8, 0.15, S.modern_earth_column(500))
+
+
+def test_config4_1024_perturbed_columns_at_full_size(O, nominal):
+    """BASELINE.json configs[3] at its stated size: 1024 perturbed ModernEarth columns (SURVEY 8(d):
+    whole-column dT ~ U(-20,20) + per-layer N(0,2 K), P x U(0.5,2), H2O and CO2 x 10^U(-1,1), seed 7),
+    200 layers, the full 1000-bin grid, 8 zenith angles, through radtran_toa_fluxes_batch.
+    A seeded subset of 16 columns is held to the oracle at the usual tolerances (level fluxes of both
+    channels, ISR, OLR); every column is held to the one-call-per-column path bit for bit."""
+    from clima_amd import synthetic as S
+    tb, r, _ = nominal
+    cols = S.perturbed_columns(1024, nz=200, seed=7)
+    isr, olr, fl = r.TOA_fluxes_batch(cols, return_fluxes=True)        # fl (nz+1, 5, ncol)
+    assert isr.shape == (1024,) and fl.shape == (201, 5, 1024)
+    assert np.all(np.isfinite(fl)) and np.all(olr > 0) and np.all(isr > 0)
+    assert np.ptp(olr) > 0.05 * np.mean(olr)                             # the sweep does move the answer
+    # ---- bitwise: batch == single calls, all 1024
+    for c, col in enumerate(cols):
+        a = r.TOA_fluxes(*col.args())
+        assert a == (isr[c], olr[c]), c
+        if c % 64 == 0:
+            np.testing.assert_array_equal(fl[:, 4, c], np.array(r.f_total))
+            np.testing.assert_array_equal(fl[:, 0, c], r.wrk_ir.fup_n)
+            np.testing.assert_array_equal(fl[:, 3, c], r.wrk_sol.fdn_n)
+    # ---- oracle: 16 seeded columns
+    o = O.OracleRadtran(tb, 200, 8, 0.15)
+    pick = np.random.default_rng(7).choice(1024, size=16, replace=False)
+    for c in pick:
+        isr_o, olr_o = o.TOA_fluxes(*cols[c].args())
+        assert abs(olr[c] - olr_o) <= 1e-9 * abs(olr_o), c               # north_star: 1e-4
+        assert abs(isr[c] - isr_o) <= 1e-9 * abs(isr_o), c
+        rows = (o.wrk_ir.fup_n, o.wrk_ir.fdn_n, o.wrk_sol.fup_n, o.wrk_sol.fdn_n, o.f_total)
+        for pair in ((0, 1), (2, 3)):
+            scale = max(np.max(np.abs(rows[pair[0]])), np.max(np.abs(rows[pair[1]])))
+            for a in pair:
+                assert np.max(np.abs(fl[:, a, c] - rows[a])) <= 1e-9 * scale, (c, a)
+        assert np.max(np.abs(fl[:, 4, c] - rows[4])) <= 1e-9 * np.max(np.abs(rows[4])), c

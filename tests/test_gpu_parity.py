@@ -368,6 +368,42 @@ def test_fused_and_separate_launch_forms(O, nz, nw, monkeypatch):
     assert not Radtran(tb, nz, 3, 0.2).fused
 
 
+def test_fused_handoff_timeout_is_reissued_unfused(O, monkeypatch):
+    """A two-stream block of the fused grid whose (bounded) wait for its opacity blocks expires must
+    not fail the call with the opacity error text: the call is computed again through the separate
+    launches.  CLIMA_HIP_FUSED_SPINS=0 makes every wait that is not satisfied at its first poll expire."""
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    tables = S.modern_earth_tables(nw=400)   # enough opacity blocks that some two-stream blocks do wait
+    nz = 200
+    col = S.modern_earth_column(nz)
+    ref = Radtran(tables, nz, 4, 0.2)
+    ref.fused = False
+    want = ref.TOA_fluxes(*col.args())
+    want_f, want_opr = np.array(ref.f_total), ref.opr()
+    monkeypatch.setenv("CLIMA_HIP_FUSED_SPINS", "0")
+    r = Radtran(tables, nz, 4, 0.2)
+    monkeypatch.delenv("CLIMA_HIP_FUSED_SPINS")
+    assert r.fused
+    got = r.TOA_fluxes(*col.args())          # synchronous API: re-issued inside the call
+    assert r.fused_fallbacks >= 1
+    assert got == want
+    np.testing.assert_array_equal(np.array(r.f_total), want_f)
+    for a, b in zip(r.opr(), want_opr):
+        np.testing.assert_array_equal(a, b)
+    # resident form: detected at the synchronise
+    n0 = r.fused_fallbacks
+    r.upload_column(*col.args())
+    r.radiate_resident()
+    r.synchronize()
+    assert r.fused_fallbacks > n0
+    np.testing.assert_array_equal(np.array(r.f_total), want_f)
+    # column batch
+    n0 = r.fused_fallbacks
+    isr, olr = r.TOA_fluxes_batch([col, col])
+    assert r.fused_fallbacks > n0 and isr[0] == want[0] and olr[1] == want[1]
+
+
 def test_state_carried_between_calls(O, small_tables):
     # compute_opacity=False reuses opr; compute_solar=False reuses wrk_sol (clima_radtran.f90:255-289)
     from clima_amd import synthetic as S
@@ -522,6 +558,21 @@ def test_error_behaviour_matches_reference(small_tables):
                   col["radii"])
     with pytest.raises(ClimaException, match="Both pdensities and radii must be arguments."):
         r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"], col["pdensities"], None)
+    # check_dimensions_p reports the two arrays separately (clima_radtran.f90:446-463) ...
+    with pytest.raises(ClimaException, match='"radii" has the wrong input dimension.'):
+        r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"], col["pdensities"],
+                  col["radii"][:-1])
+    with pytest.raises(ClimaException, match='"pdensities" has the wrong input dimension.'):
+        r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"], col["pdensities"][:-1],
+                  col["radii"])
+    # ... and after the gas arrays (:441-445)
+    with pytest.raises(ClimaException, match='"dz" has the wrong input dimension.'):
+        r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"][:-1], col["pdensities"],
+                  col["radii"][:-1])
+    r.has_hard_surface = False
+    assert r.has_hard_surface is False
+    r.has_hard_surface = True
+    assert r.has_hard_surface is True
     # particle radius outside the Mie grid -> every bin flags ierr (types.f90:973-976, :773-776)
     with pytest.raises(ClimaException, match="Opacity computation failed in one or more wavelength bins."):
         r.radiate(col["T_surface"], col["T"], col["P"], col["densities"], col["dz"], col["pdensities"],
