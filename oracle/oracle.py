@@ -262,21 +262,21 @@ class OracleRadtran:
 
 # ---------------------------------------------------------------- unit-level wrappers
 
-def two_stream_ir(tau, w0, gt, emissivity, has_hard_surface, tau_min, bplanck):
+def two_stream_ir(tau, w0, gt, emissivity, has_hard_surface, tau_min, bplanck, variant=""):
     nz = len(tau)
     a = [_arr(tau), _arr(w0), _arr(gt), _arr(bplanck)]
     fup, fdn = np.empty(nz + 1), np.empty(nz + 1)
-    lib().orc_two_stream_ir(nz, a[0][1], a[1][1], a[2][1], emissivity, int(has_hard_surface), tau_min, a[3][1],
+    lib(variant).orc_two_stream_ir(nz, a[0][1], a[1][1], a[2][1], emissivity, int(has_hard_surface), tau_min, a[3][1],
                             fup.ctypes.data_as(_dp), fdn.ctypes.data_as(_dp))
     return fup, fdn
 
 
-def two_stream_solar(tau, w0, gt, u0, Rsfc):
+def two_stream_solar(tau, w0, gt, u0, Rsfc, variant=""):
     nz = len(tau)
     a = [_arr(tau), _arr(w0), _arr(gt)]
     amean, fup, fdn = np.empty(nz + 1), np.empty(nz + 1), np.empty(nz + 1)
     sr = C.c_double()
-    lib().orc_two_stream_solar(nz, a[0][1], a[1][1], a[2][1], u0, Rsfc, amean.ctypes.data_as(_dp), C.byref(sr),
+    lib(variant).orc_two_stream_solar(nz, a[0][1], a[1][1], a[2][1], u0, Rsfc, amean.ctypes.data_as(_dp), C.byref(sr),
                                fup.ctypes.data_as(_dp), fdn.ctypes.data_as(_dp))
     return amean, sr.value, fup, fdn
 

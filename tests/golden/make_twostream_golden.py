@@ -7,9 +7,13 @@ oracle/Makefile compiles with amdflang, unmodified, from
 (two_stream_ir :156-295, two_stream_solar :10-154, tridiag :297-316).  Only inputs and the
 reference's outputs are stored (data, no source).
 
-Cases cover: nz = 1, 2, 3, 7, 50, 200; optically thin (tau ~ 1e-8, below ir_tau_min) to
+Cases 0-35 cover: nz = 1, 2, 3, 7, 50, 200; optically thin (tau ~ 1e-8, below ir_tau_min) to
 thick (tau ~ 1e3, exp underflow); w0 from 0 to the cap 0.99999; g up to the cap 0.999999;
-hard / no hard surface; emissivity < 1; grazing and overhead sun; albedo 0 and 1.
+hard / no hard surface; emissivity < 1; grazing and overhead sun; albedo 0 and 1.  Their Planck
+values are random over four decades from level to level, which makes the IR source slope
+(B_{i+1}-B_i)/tau of thin layers deliberately ill-conditioned.
+Cases 36-67: smooth Planck profiles and pressure-like optical depths (the shape of a real call) at
+nz = 1 ... 512, including every chunk edge of the 64-lane decomposition.
 """
 import os
 import sys
@@ -50,6 +54,34 @@ def main():
             fup, fdn = O.ref_two_stream_ir(tau, w0, g, em, hs, 1e-6, bp)
             u0 = [0.5, 0.02, 1.0, 0.3, 0.9, 0.7][variant]
             rs = [0.3, 0.0, 1.0, 0.15, 0.5, 0.9][variant]
+            am, sr, sfup, sfdn = O.ref_two_stream_solar(tau, w0, g, u0, rs)
+            k = "c%02d_" % n
+            out.update({k + "tau": tau, k + "w0": w0, k + "g": g, k + "bplanck": bp,
+                        k + "ir_par": np.array([em, float(hs), 1e-6]), k + "ir_fup": fup, k + "ir_fdn": fdn,
+                        k + "sol_par": np.array([u0, rs]), k + "sol_amean": am, k + "sol_sr": np.array([sr]),
+                        k + "sol_fup": sfup, k + "sol_fdn": sfdn})
+            n += 1
+    # ---- cases 36...: smooth Planck profiles (B_nu of a lapse-rate temperature profile at one
+    # frequency, as radiate.f90:63-69 hands them over) and optical depths that grow with pressure --
+    # the well-conditioned shape of a real call -- at column heights that reach every slot count of
+    # the wave kernels (64 layers per slot: 1...8), including the chunk edges 64/65, 128/129, 256/257.
+    rng2 = np.random.default_rng(20261004)
+    h, kb, cl = 6.62607004e-34, 1.380649e-23, 299792458.0
+    for nz in (1, 5, 50, 64, 65, 128, 129, 192, 200, 256, 257, 300, 402, 448, 500, 512):
+        for variant in range(2):
+            lev = np.linspace(0.0, 1.0, nz + 1)                      # TOA -> ground
+            T = 180.0 + 110.0 * lev ** (1.0 if variant == 0 else 2.5) + rng2.uniform(-1.0, 1.0, nz + 1)
+            nu = [2.0e13, 6.0e13][variant]
+            bp = 1.0e3 * ((2.0 * h * nu ** 3) / cl ** 2) / (np.exp((h * nu) / (kb * T)) - 1.0)
+            mid = 0.5 * (lev[1:] + lev[:-1])
+            tau = (10.0 ** rng2.uniform(-3, 1.5)) * (mid ** 2 + 1e-4) / nz * 40.0 * 10 ** rng2.uniform(-0.3, 0.3, nz)
+            w0 = rng2.uniform(0.0, 0.9 if variant == 0 else 0.3, nz)
+            g = rng2.uniform(0.0, 0.85, nz)
+            hs = variant == 0
+            em = 1.0 if variant == 0 else 0.9
+            fup, fdn = O.ref_two_stream_ir(tau, w0, g, em, hs, 1e-6, bp)
+            u0 = [0.6, 0.25][variant]
+            rs = [0.2, 0.6][variant]
             am, sr, sfup, sfdn = O.ref_two_stream_solar(tau, w0, g, u0, rs)
             k = "c%02d_" % n
             out.update({k + "tau": tau, k + "w0": w0, k + "g": g, k + "bplanck": bp,
