@@ -23,14 +23,14 @@ namespace clima {
 
 // hipFuncAttributeMaxDynamicSharedMemorySize = 160 KiB, once per (device, kernel).  false when the
 // runtime refuses it (the error stays in hipGetLastError for the caller to report).
-static bool ensure_max_lds(const void *fn) {
+static bool ensure_max_lds(const void *fn, int bytes = 160 * 1024) {
   static std::mutex mu;
   static std::set<std::pair<int, const void *>> done;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   std::lock_guard<std::mutex> lk(mu);
   if (done.count({dev, fn})) return true;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
   done.insert({dev, fn});
   return true;
 }
@@ -54,7 +54,7 @@ static int device_cus() {
 #define STAMP(buf, slot)                                                          \
   do {                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                            \
-    if ((buf) && blockIdx.x == 100 && threadIdx.x == 0) (buf)[slot] = __builtin_amdgcn_s_memtime(); \
+    if ((buf) && tile == 100 && threadIdx.x == 0) (buf)[slot] = __builtin_amdgcn_s_memtime(); \
     __builtin_amdgcn_sched_barrier(0);                                            \
   } while (0)
 #else
@@ -217,61 +217,33 @@ __device__ __forceinline__ int bracket(const double *xt, int n, double x) {
 
 // ------------------------------------------------------------------------------------
 // k_prep: block 0 writes the per-layer column quantities; block b>=1 evaluates
-// interpolation slot b-1 for every layer (axis staged in LDS).  Every block re-derives
-// pair_reuse locally, so there is no inter-block dependency.
+// interpolation slot b-1 for every layer (axis staged in LDS).  pair_reuse (types.f90:621-632)
+// arrives with the column (decided on the host at upload, ColumnDev::meta), so there is no
+// inter-block dependency.  gridDim.y = columns of a batch.
 // ------------------------------------------------------------------------------------
 constexpr int PREP_AXIS_MAX = 1024;
 constexpr int PREP_ZERO_BLOCKS = 32;  // blocks per output array cleared by the prep launch
 
-// source layer for interpolation: j, or j-1 when (j-1,j) is a reusable pair (types.f90:621-632).
-// Every operand is loaded before the first comparison and the predicates are and-ed without
-// short circuit, so the ~20 loads of a layer overlap instead of forming a chain of misses (the
-// column has just arrived by DMA: nothing of it is in a cache yet).
-__device__ __forceinline__ int reuse_source(const PrepParams &p, int j) {
-  const int nz = p.nz;
-  const ColumnDev &c = p.col;
-  if ((nz & 1) != 0 || (j & 1) == 0) return j;
-  const double tol = 1.0e-12;
-  const double Pj = c.P[j], Pm = c.P[j - 1], Tj = c.T[j], Tm = c.T[j - 1];
-  const double dzj = c.dz[j], dzm = c.dz[j - 1];
-  int ok = 1;  // and-ed as integers: no short circuit
-  for (int i0 = 0; i0 < p.nsp; i0 += 8) {
-    double a[8], b[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {  // past the last species: the last one again (same predicate)
-      const int i = min(i0 + k, p.nsp - 1);
-      a[k] = c.dens[i * nz + j];
-      b[k] = c.dens[i * nz + j - 1];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) ok &= (int)is_close(a[k] * dzj, b[k] * dzm, tol);
-  }
-  if (p.check_radii) {
-    for (int i0 = 0; i0 < p.np; i0 += 4) {
-      double a[4], b[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int i = min(i0 + k, p.np - 1);
-        a[k] = c.radii[i * nz + j];
-        b[k] = c.radii[i * nz + j - 1];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) ok &= (int)is_close(a[k], b[k], tol);
-    }
-  }
-  ok &= (int)is_close(Pj, Pm, tol);
-  ok &= (int)is_close(Tj, Tm, tol);
-  return ok ? j - 1 : j;
+// column `cb` of a batch: every per-column pointer moved by that column's stride
+__device__ __forceinline__ ColumnDev column_at(const ColumnDev &c0, const BatchStrides &bs, const int cb) {
+  ColumnDev c = c0;
+  const size_t oc = (size_t)cb * bs.col, op = (size_t)cb * bs.prep;
+  c.T += oc; c.P += oc; c.dz += oc; c.dens += oc; c.pdens += oc; c.radii += oc; c.T_surface += oc;
+  c.meta += 2 * oc;
+  c.log10P += op; c.cols += op; c.foreign_col += op; c.absw += op; c.q += op;
+  c.ix += 2 * op;
+  return c;
 }
 
 __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
   __shared__ double s_axis[PREP_AXIS_MAX];
   const int nz = p.nz;
-  const ColumnDev &c = p.col;
+  const int cb = blockIdx.y;
+  const ColumnDev c = column_at(p.col, p.bs, cb);
+  const int *src = c.meta + 1 + nz;  // source layer of every layer (pair_reuse, decided on the host)
   if (blockIdx.x == 0) {
     for (int j = threadIdx.x; j < nz; j += blockDim.x) {
       const double Pj = c.P[j], dzj = c.dz[j];
-      const int src = reuse_source(p, j);
       double fc = 0.0;
       for (int i0 = 0; i0 < p.nsp; i0 += 8) {  // :607-619, loads of a batch issued together
         double d[8];
@@ -289,7 +261,6 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
       }
       c.log10P[j] = log10(Pj);  // types.f90:605
       c.foreign_col[j] = fc;
-      c.src[j] = src;
     }
     return;
   }
@@ -297,7 +268,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
     // spare blocks clear the output spectra that the two-stream kernel accumulates into
     const int zb = (int)blockIdx.x - (p.nslots + p.nabs + 1);
     const int arr = zb / PREP_ZERO_BLOCKS, part = zb - arr * PREP_ZERO_BLOCKS;
-    double *dst = p.zero_ptr[arr];
+    double *dst = p.zero_ptr[arr] + (size_t)cb * p.bs.res;
     const size_t n = p.zero_count[arr];
     for (size_t i = (size_t)part * blockDim.x + threadIdx.x; i < n; i += (size_t)PREP_ZERO_BLOCKS * blockDim.x) dst[i] = 0.0;
     return;
@@ -329,14 +300,11 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
   const bool in_lds = sl.n <= PREP_AXIS_MAX;
   if (in_lds)
     for (int i = threadIdx.x; i < sl.n; i += blockDim.x) s_axis[i] = sl.axis[i];
-  // the first layer's source is looked up while the axis loads are in flight
-  // custom optical properties are evaluated for every layer itself (types.f90:564-569)
-  int js_first = threadIdx.x;
-  if ((int)threadIdx.x < nz && sl.source >= 0) js_first = reuse_source(p, threadIdx.x);
   __syncthreads();
   const double *axis = in_lds ? s_axis : sl.axis;
   for (int j = threadIdx.x; j < nz; j += blockDim.x) {
-    const int js = j == (int)threadIdx.x ? js_first : (sl.source < 0 ? j : reuse_source(p, j));
+    // custom optical properties are evaluated for every layer itself (types.f90:564-569)
+    const int js = sl.source < 0 ? j : src[j];
     double x;
     if (sl.source < 0) x = log10(c.P[js] * 1.0e6);  // log10P_cgs, types.f90:606
     else if (sl.source == 0) x = log10(c.P[js]);
@@ -351,7 +319,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
 }
 
 void launch_prep(const PrepParams &p, hipStream_t s) {
-  hipLaunchKernelGGL(k_prep, dim3(1 + p.nslots + p.nabs + p.nzero * PREP_ZERO_BLOCKS), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_prep, dim3(1 + p.nslots + p.nabs + p.nzero * PREP_ZERO_BLOCKS, p.ncol > 0 ? p.ncol : 1), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------
@@ -404,9 +372,93 @@ __device__ int g_stamp_step = 0;
 // function; whenever c passes an output edge E_k the integral up to that edge,
 // I_k = S + v*(E_k - c0), is written to the lane's private LDS slot k.  The new coefficients
 // are (I_k - I_{k-1}) / (E_k - E_{k-1}).
-template <bool MULTI>
+// Rebin form RM = 0 ("window" form, the default): the integral of the sorted step function is convex
+// and piecewise linear in the cumulative weight c, with ascending slopes (the sorted keys), so it is
+// the maximum of the lines through its pieces,
+//     I(E_k) = max_j [ IC_{j-1} + v_j * (E_k - C_{j-1}) ],   C = running weight, IC = running integral,
+// and the maximising j is the element that crosses E_k -- whose term is exactly the expression the
+// streaming form evaluates there.  No search, no branch, no LDS slots: one subtract, one fma, one max
+// per (element, edge) pair.  Only pairs that CAN be a crossing are evaluated: whatever order the sort
+// produces, C_j lies between the sum of the j+1 smallest and the j+1 largest pair weights, which
+// bounds the crossing element of edge k to a window [rb_lo(k), rb_hi(k)] -- 144 pairs instead of 448
+// for 8 Gauss-Legendre weights (tools/gen_rebin_windows.py prints the tables; the host checks the
+// handle's actual weights against them and otherwise selects the streaming form, RM = 1 or 2).  A
+// window wider than necessary is harmless (every line lies below the integral).
+// Two window tables.  WIDE: any order of the 64 sums (bounds over arbitrary subsets of the pair
+// weights): 144 pairs.  TIGHT: x and y both ascending (the wave-uniform `xys` case, which is the
+// normal one: k-coefficients ascend in g, and so does a rebinned mixture): the sorted order is then a
+// linear extension of the 8x8 product order, every prefix is a down-set (a Young diagram) of the
+// grid, and the bounds over down-sets of each size confine the crossings to 52 pairs.
+template <bool TIGHT>
+constexpr int rb_lo(int k) {
+  constexpr int wide[8] = {0, 1, 5, 10, 18, 27, 39, 52};
+  constexpr int tight[8] = {0, 5, 12, 19, 27, 35, 45, 55};
+  return TIGHT ? tight[k] : wide[k];
+}
+template <bool TIGHT>
+constexpr int rb_hi(int k) {
+  constexpr int wide[8] = {0, 11, 24, 36, 45, 53, 58, 62};
+  constexpr int tight[8] = {0, 8, 18, 28, 36, 44, 51, 58};
+  return TIGHT ? tight[k] : wide[k];
+}
+
+// One straight-line pass serves both tables: the pairs of the tight table always, the pairs that only
+// the wide table holds under a wave-uniform `if (!xys)` per element (two separate unrolled passes
+// behind one branch cost the register allocator 40 spilled registers).
+__device__ __forceinline__ void rebin_window(const double (&key)[64], const bool xys, const double *s_wxy,
+                                             const double (&E)[9], const double (&rW)[8], double (&out)[8]) {
+  double C = 0.0, IC = 0.0, Ie[9];
+#pragma unroll
+  for (int k = 1; k < 8; k++) Ie[k] = -1.0e300;  // below every candidate (the sums are finite)
+  constexpr int RB = 8;
+  double wn[RB];
+#pragma unroll
+  for (int u = 0; u < RB; u++) wn[u] = s_wxy[(int)((unsigned long long)__double_as_longlong(key[u]) & 63ULL)];
+#pragma unroll
+  for (int pb = 0; pb < 64; pb += RB) {
+    double wv[RB];
+#pragma unroll
+    for (int u = 0; u < RB; u++) wv[u] = wn[u];
+    if (pb + RB < 64) {
+#pragma unroll
+      for (int u = 0; u < RB; u++)
+        wn[u] = s_wxy[(int)((unsigned long long)__double_as_longlong(key[pb + RB + u]) & 63ULL)];
+    }
+#pragma unroll
+    for (int u = 0; u < RB; u++) {
+      const int j = pb + u;
+      const double v = key[j];
+#pragma unroll
+      for (int k = 1; k < 8; k++) {
+        if (j >= rb_lo<true>(k) && j <= rb_hi<true>(k))
+          Ie[k] = dmax(Ie[k], __builtin_fma(v, E[k] - C, IC));
+      }
+      bool wide_only = false;
+#pragma unroll
+      for (int k = 1; k < 8; k++)
+        wide_only = wide_only || (j >= rb_lo<false>(k) && j <= rb_hi<false>(k) && !(j >= rb_lo<true>(k) && j <= rb_hi<true>(k)));
+      if (wide_only) {
+        if (!xys) {
+#pragma unroll
+          for (int k = 1; k < 8; k++) {
+            if (j >= rb_lo<false>(k) && j <= rb_hi<false>(k) && !(j >= rb_lo<true>(k) && j <= rb_hi<true>(k)))
+              Ie[k] = dmax(Ie[k], __builtin_fma(v, E[k] - C, IC));
+          }
+        }
+      }
+      IC = __builtin_fma(v, wv[u], IC);  // weights_to_bins (clima_eqns.f90:43-54) and the integral, in sorted order
+      C = C + wv[u];
+    }
+  }
+  Ie[8] = IC;  // the last edge is the total weight
+  out[0] = Ie[1] * rW[0];
+#pragma unroll
+  for (int q = 1; q < 8; q++) out[q] = (Ie[q + 1] - Ie[q]) * rW[q];
+}
+
+template <int RM>
 __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y)[8],
-                                          double (*sI)[OP_THREADS], const int tid,
+                                          double (*sI)[OP_THREADS], const int tid, const int tile,
                                           const double *s_wxy, const double *s_E,
                                           const double (&E)[9], const double (&rW)[8],
                                           double (&out)[8]) {
@@ -471,6 +523,11 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
 #undef CE_X
 #undef CE
   STAMP(g_stamp_buf, 30 + g_stamp_step);
+  if constexpr (RM == 0) {
+    rebin_window(key, xys, s_wxy, E, rW, out);
+    return;
+  }
+  constexpr bool MULTI = RM == 2;
   double S = 0.0, c0 = 0.0;
   // Next output edge to pass is E[k]: bk = E[k], `en` points at E[k+1] in the LDS edge table and
   // bn = *en is prefetched; `slot` is where I(E_k) goes.  Running pointers instead of k keep the
@@ -529,10 +586,30 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
   for (int q = 1; q < 8; q++) out[q] = (Ik[q] - Ik[q - 1]) * rW[q];
 }
 
-template <bool MULTI, bool CUSTOM, bool COHERENT>
-__device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int block) {
+// Layer terms that are not k-distributions (types.f90:665-757)
+struct LayerTerms {
+  double tausg, taua, tauc, tausc, taup, tausp, gt;
+};
+
+// One tile of 256 lanes, one lane per (bin, SOURCE layer): a layer that pair_reuse marks as a copy of
+// the layer below it (types.f90:621-632; AdiabatClimate's doubled radiative grid is all such pairs,
+// src/adiabat/clima_adiabat.f90:729-773) has no lane of its own -- its source's lane writes both
+// layers.  What the reference copies for the second layer is the interpolated k-coefficients and
+// cross sections and the rebinned mixture (:652-653, :833-834, :907-908, :933-935); its columns and
+// particle terms are its own.  When every input of the two layers is bitwise equal (SRC_EXACT: what
+// the doubled grid produces) all of that is equal too and the lane stores its results twice;
+// otherwise it evaluates the second layer's own terms before storing.
+// `c` and the opr pointers are those of the tile's column (column_at / + c*bs.opr in a batch).
+template <int RM, bool CUSTOM, bool COHERENT>
+__device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int tile, const size_t oc,
+                                              const size_t opf, const size_t oo) {
+  // column arrays at c.X[oc + ...] (ints: 2*oc), prep arrays at c.X[opf + ...] (ints: 2*opf), optical
+  // properties at p.X[oo + ...]: the offsets of the tile's column in a batch (0 for a single call).
+  // Offsets at the point of use rather than 15 shifted pointers up front: those would sit in scalar
+  // registers for the whole tile, and the tile has none to spare.
+  const ColumnDev &c = p.col;
   constexpr int NG = 8;
-  __shared__ double sI[NG][OP_THREADS];  // per-lane private slots (slot-major: conflict-free)
+  __shared__ double sI[RM == 0 ? 1 : NG][OP_THREADS];  // streaming rebin: per-lane private slots (slot-major: conflict-free)
   __shared__ double s_wxy[NG * NG];
   __shared__ double s_E[NG + 4];  // output edges followed by +inf sentinels
   const int tid = threadIdx.x;
@@ -552,16 +629,16 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   const long long wt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const int nz = p.nz;
-  const long total = (long)p.nbins * nz;
-  const ColumnDev &c = p.col;
-  long t = (long)block * OP_THREADS + tid;
+  const int nsrc = c.meta[2 * oc + 0];
+  const long total = (long)p.nbins * nsrc;
+  long t = (long)tile * OP_THREADS + tid;
   const bool valid = t < total;
   if (!valid) t = total - 1;
-  const int l = p.bin_lo + (int)(t / nz);
-  const int j = (int)(t % nz);  // ground-first layer
-  const int n = nz - 1 - j;     // TOA-first index (types.f90:690-691, :862-865)
-  const bool reuse = c.src[j] != j;
-  const double dzj = c.dz[j];
+  const int l = p.bin_lo + (int)(t / nsrc);
+  const int ent = c.meta[2 * oc + 1 + (int)(t % nsrc)];
+  const int j = ent & SRC_LAYER;  // ground-first layer
+  const bool pair = (ent & SRC_PAIR) != 0, exact = (ent & SRC_EXACT) != 0;
+  const int n = nz - 1 - j;       // TOA-first index (types.f90:690-691, :862-865)
 
   STAMP(p.stamps, 0);
   // Everything of the layer that is not a k-distribution (Rayleigh, continuum, custom and particle
@@ -569,16 +646,16 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   // loop.  The two waves that share a SIMD take opposite orders (hardware wave-slot parity): one
   // is in this load-latency-bound part while the other is in the VALU-bound sort/rebin, instead of
   // both stalling on memory at the same time.
-  double tausg, taua, tauc, tausc, taup, tausp, gt;
-  auto layer_terms = [&]() {
+  auto layer_terms = [&](const int jl, LayerTerms &o) {
+    const double dzj = c.dz[oc + jl];
     // ---- Rayleigh (:686-693)
-    tausg = 0.0;
+    double tausg = 0.0;
   #pragma unroll 4
-    for (int i = 0; i < p.nray; i++) tausg = tausg + p.ray[i].data[l] * c.cols[p.ray[i].sp1 * nz + j];
+    for (int i = 0; i < p.nray; i++) tausg = tausg + p.ray[i].data[l] * c.cols[opf + p.ray[i].sp1 * nz + jl];
     // ---- continuum absorption: CIA, photolysis/absorption, H2O continuum (:665-677, :696-723).
     // Entries are processed eight at a time with every load of the batch issued before the
     // first use, so the dependent index -> table round trips overlap instead of queueing.
-    taua = 0.0;
+    double taua = 0.0;
     constexpr int AB = 8;
     for (int e0 = 0; e0 < p.nabs; e0 += AB) {
       int ixx[AB];
@@ -586,9 +663,9 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   #pragma unroll
       for (int u = 0; u < AB; u++) {
         const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
-        ixx[u] = c.ix[x.slot * nz + j];
-        qq[u] = c.q[x.slot * nz + j];
-        ww[u] = c.absw[min(e0 + u, p.nabs - 1) * nz + j];
+        ixx[u] = c.ix[2 * opf + x.slot * nz + jl];
+        qq[u] = c.q[opf + x.slot * nz + jl];
+        ww[u] = c.absw[opf + min(e0 + u, p.nabs - 1) * nz + jl];
       }
       double v0[AB], v1[AB];
   #pragma unroll
@@ -609,11 +686,11 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
       }
     }
     // ---- custom opacity (:540-572, :726-730); tiny everywhere when unset (:558-562)
-    tauc = TINY; tausc = TINY * TINY;
+    double tauc = TINY, tausc = TINY * TINY;
     double g0c = TINY;
     if constexpr (CUSTOM) {
-      const int ix = c.ix[p.cust.slot * nz + j];
-      const double q = c.q[p.cust.slot * nz + j];
+      const int ix = c.ix[2 * opf + p.cust.slot * nz + jl];
+      const double q = c.q[opf + p.cust.slot * nz + jl];
       const size_t o = (size_t)l * p.cust.nP;
       tauc = lerp1(p.cust.dtau + o, ix, q) * dzj;
       const double w0c = lerp1(p.cust.w0 + o, ix, q);
@@ -621,55 +698,44 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
       tausc = w0c * tauc;
     }
     // ---- particles (:680-683, :733-757)
-    tausp = 0.0; taup = 0.0;
+    double tausp = 0.0, taup = 0.0;
     double tausp_1[MAX_PART], gtp[MAX_PART];
     for (int i = 0; i < p.npart; i++) {
       const PartDev &pt = p.part[i];
-      const int ix = c.ix[pt.slot * nz + j];
-      const double q = c.q[pt.slot * nz + j];
+      const int ix = c.ix[2 * opf + pt.slot * nz + jl];
+      const double q = c.q[opf + pt.slot * nz + jl];
       const double w0p = lerp1(pt.w0 + (size_t)l * pt.nrad, ix, q);
       const double qext = lerp1(pt.qext + (size_t)l * pt.nrad, ix, q);
       gtp[i] = lerp1(pt.gt + (size_t)l * pt.nrad, ix, q);
-      const double rr = c.radii[pt.p_ind * nz + j];
-      const double taup_1 = qext * PI * (rr * rr) * c.pdens[pt.p_ind * nz + j] * dzj;
+      const double rr = c.radii[oc + pt.p_ind * nz + jl];
+      const double taup_1 = qext * PI * (rr * rr) * c.pdens[oc + pt.p_ind * nz + jl] * dzj;
       taup = taup + taup_1;
       tausp_1[i] = w0p * taup_1;
       tausp = tausp + tausp_1[i];
     }
-    gt = 0.0;
+    double gt = 0.0;
     for (int i = 0; i < p.npart; i++) gt = gt + gtp[i] * tausp_1[i] / fmax(TAU_MIN, (tausp + tausg + tausc));
     gt = gt + g0c * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
     gt = fmin(gt, MAX_GT);
-
+    o.tausg = tausg; o.taua = taua; o.tauc = tauc; o.tausc = tausc; o.taup = taup; o.tausp = tausp; o.gt = gt;
   };
+  LayerTerms lt;
   const bool terms_first = (__builtin_amdgcn_s_getreg(HWREG_HW_ID_WAVE_ID) & 1) == 0;
-  if (terms_first) layer_terms();
+  if (terms_first) layer_terms(j, lt);
 
   STAMP(p.stamps, 1);
   // ---- k-distributions (:649-662) and random-overlap mixing (k_rorr :816-854)
-  double tk[NG];  // tau_k of the running mixture
-#pragma unroll
-  for (int g = 0; g < NG; g++) tk[g] = 0.0;
-  // interpolation brackets of the next species are fetched while the current one is mixed
-  int iP_n = c.ix[p.k[0].slotP * nz + j], iT_n = c.ix[p.k[0].slotT * nz + j];
-  double q1_n = c.q[p.k[0].slotP * nz + j], q2_n = c.q[p.k[0].slotT * nz + j];
-  for (int s = 0; s < p.nk; s++) {
+  // g-point coefficients of species s times the column of layer jl
+  auto k_times_col = [&](const int s, const int jl, const int iP, const int iT, const double q1, const double q2,
+                         double (&kc)[NG]) {
     const KDev &kd = p.k[s];
-    const int iP = iP_n, iT = iT_n;
-    const double q1 = q1_n, q2 = q2_n;
-    if (s + 1 < p.nk) {
-      const KDev &kn = p.k[s + 1];
-      iP_n = c.ix[kn.slotP * nz + j]; iT_n = c.ix[kn.slotT * nz + j];
-      q1_n = c.q[kn.slotP * nz + j]; q2_n = c.q[kn.slotT * nz + j];
-    }
     const double p1 = 1.0 - q1, p2 = 1.0 - q2;
     const double *slab = kd.log10k + (size_t)l * kd.nT * kd.nP * NG;
     const double *f11 = slab + ((size_t)iT * kd.nP + iP) * NG;
     const double *f21 = f11 + NG;                    // iP+1
     const double *f12 = f11 + (size_t)kd.nP * NG;    // iT+1
     const double *f22 = f12 + NG;
-    const double col = c.cols[kd.sp * nz + j];
-    double kc[NG];
+    const double col = c.cols[opf + kd.sp * nz + jl];
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       // linear_interp_2d%evaluate, linear_interpolation_module.F90:319-327
@@ -677,58 +743,90 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
       const double fx2 = p1 * f12[g] + q1 * f22[g];
       kc[g] = ten2power(p2 * fx1 + q2 * fx2) * col;  // :818 / :828
     }
+  };
+  double tk[NG];  // tau_k of the running mixture
+#pragma unroll
+  for (int g = 0; g < NG; g++) tk[g] = 0.0;
+  // interpolation brackets of the next species are fetched while the current one is mixed
+  int iP_n = c.ix[2 * opf + p.k[0].slotP * nz + j], iT_n = c.ix[2 * opf + p.k[0].slotT * nz + j];
+  double q1_n = c.q[opf + p.k[0].slotP * nz + j], q2_n = c.q[opf + p.k[0].slotT * nz + j];
+  for (int s = 0; s < p.nk; s++) {
+    const int iP = iP_n, iT = iT_n;
+    const double q1 = q1_n, q2 = q2_n;
+    if (s + 1 < p.nk) {
+      const KDev &kn = p.k[s + 1];
+      iP_n = c.ix[2 * opf + kn.slotP * nz + j]; iT_n = c.ix[2 * opf + kn.slotT * nz + j];
+      q1_n = c.q[opf + kn.slotP * nz + j]; q2_n = c.q[opf + kn.slotT * nz + j];
+    }
+    double kc[NG];
+    k_times_col(s, j, iP, iT, q1, q2, kc);
     STAMP(p.stamps, 2 + 3 * s);
     if (s == 0) {
 #pragma unroll
       for (int g = 0; g < NG; g++) tk[g] = kc[g];
     } else {
 #ifdef CLIMA_STAMPS
-      if (blockIdx.x == 100 && threadIdx.x == 0) { g_stamp_buf = p.stamps; g_stamp_step = s; }
+      if (tile == 100 && threadIdx.x == 0) { g_stamp_buf = p.stamps; g_stamp_step = s; }
 #endif
       double out[NG];
-      rorr_mix8<MULTI>(tk, kc, sI, tid, s_wxy, s_E, E, rW, out);
-      // pair_reuse: the second layer of a pair copies the first layer's rebinned
-      // mixture (:833-834).  Layer j-1 of the same bin lives in lane-1 (nz even).
+      rorr_mix8<RM>(tk, kc, sI, tid, tile, s_wxy, s_E, E, rW, out);
 #pragma unroll
-      for (int g = 0; g < NG; g++) {
-        const double prev = __shfl_up(out[g], 1);
-        tk[g] = reuse ? prev : out[g];
-      }
+      for (int g = 0; g < NG; g++) tk[g] = out[g];
       STAMP(p.stamps, 4 + 3 * s);
     }
   }
-  if (!terms_first) layer_terms();
+  if (!terms_first) layer_terms(j, lt);
   STAMP(p.stamps, 20);
 #ifdef CLIMA_STAMPS
   if (p.stamps && (tid & 63) == 0) {
-    const long w = (long)block * (OP_THREADS / 64) + (tid >> 6);
+    const long w = (long)tile * (OP_THREADS / 64) + (tid >> 6);
     p.stamps[64 + 2 * w] = wt0;
     p.stamps[64 + 2 * w + 1] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
 
   // ---- totals (:856-886)
-  if (valid) {
+  auto store_layer = [&](const int nn, const LayerTerms &T, const double (&tkv)[NG]) {
     double tb = 0.0;
-    const size_t base = ((size_t)l * NG) * nz + n;
+    const size_t base = ((size_t)l * NG) * nz + nn;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-      const double tau = tausg + taua + taup + tk[g] + tauc;
+      const double tau = T.tausg + T.taua + T.taup + tkv[g] + T.tauc;
       double w0;
       if (tau <= TAU_MIN) w0 = 0.0;
-      else w0 = fmin(MAX_W0, (tausg + tausp + tausc) / tau);
-      st_opr<COHERENT>(&p.tau[base + (size_t)g * nz], tau);
-      st_opr<COHERENT>(&p.w0[base + (size_t)g * nz], w0);
+      else w0 = fmin(MAX_W0, (T.tausg + T.tausp + T.tausc) / tau);
+      st_opr<COHERENT>(&p.tau[oo + base + (size_t)g * nz], tau);
+      st_opr<COHERENT>(&p.w0[oo + base + (size_t)g * nz], w0);
       tb = tb + tau * wbin[g];
     }
-    st_opr<COHERENT>(&p.tau_band[(size_t)l * nz + n], tb);
-    st_opr<COHERENT>(&p.g[(size_t)l * nz + n], gt);
+    st_opr<COHERENT>(&p.tau_band[oo + (size_t)l * nz + nn], tb);
+    st_opr<COHERENT>(&p.g[oo + (size_t)l * nz + nn], T.gt);
+  };
+  if (valid) {
+    store_layer(n, lt, tk);
+    if (pair) {
+      // the second layer of the pair (ground-first j+1, TOA-first n-1)
+      if (exact) {
+        store_layer(n - 1, lt, tk);
+      } else {
+        LayerTerms lt2;
+        layer_terms(j + 1, lt2);
+        if (p.nk == 1) {  // no mixing step to copy: k of the source layer times this layer's own column (:818)
+          double tk2[NG];
+          k_times_col(0, j + 1, c.ix[2 * opf + p.k[0].slotP * nz + j], c.ix[2 * opf + p.k[0].slotT * nz + j], c.q[opf + p.k[0].slotP * nz + j],
+                      c.q[opf + p.k[0].slotT * nz + j], tk2);
+          store_layer(n - 1, lt2, tk2);
+        } else {
+          store_layer(n - 1, lt2, tk);
+        }
+      }
+    }
   }
 }
 
-template <bool MULTI, bool CUSTOM>
+template <int RM, bool CUSTOM>
 __global__ __launch_bounds__(OP_THREADS, 2) void k_opacity8(OpacityParams p) {
-  opacity8_body<MULTI, CUSTOM, false>(p, (int)blockIdx.x);
+  opacity8_body<RM, CUSTOM, false>(p, (int)blockIdx.x, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -763,7 +861,7 @@ __global__ __launch_bounds__(64) void k_opacity_generic(OpacityParams p, int N2)
   const double dzj = c.dz[j];
   // the second layer of a reused pair takes the rebinned mixture of the first (:833-834);
   // with nk >= 2 its final mixture depends on the first layer's inputs only
-  const int jk = (p.nk >= 2) ? c.src[j] : j;
+  const int jk = (p.nk >= 2) ? c.meta[1 + nz + j] : j;
 
   // ---- wave-uniform terms (same statements as k_opacity8)
   double tausg = 0.0;
@@ -913,7 +1011,7 @@ __global__ __launch_bounds__(64) void k_opacity_generic(OpacityParams p, int N2)
 }
 
 bool launch_opacity(const OpacityParams &p, hipStream_t s) {
-  const long total = (long)p.nbins * p.nz;
+  long total = (long)p.nbins * p.nz;
   if (p.ng != 8) {
     if (p.ng < 1 || p.ng > OPG_MAX_NG) return false;
     if (total <= 0) return true;
@@ -923,15 +1021,13 @@ bool launch_opacity(const OpacityParams &p, hipStream_t s) {
     hipLaunchKernelGGL(k_opacity_generic, dim3((unsigned)total), dim3(64), lds, s, p, N2);
     return true;
   }
+  total = (long)p.nbins * p.nsrc;  // one lane per (bin, source layer)
   if (total <= 0) return true;
   const int grid = (int)((total + OP_THREADS - 1) / OP_THREADS);
-  if (p.cust.on) {
-    if (p.multi_edge) hipLaunchKernelGGL((k_opacity8<true, true>), dim3(grid), dim3(OP_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((k_opacity8<false, true>), dim3(grid), dim3(OP_THREADS), 0, s, p);
-  } else {
-    if (p.multi_edge) hipLaunchKernelGGL((k_opacity8<true, false>), dim3(grid), dim3(OP_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((k_opacity8<false, false>), dim3(grid), dim3(OP_THREADS), 0, s, p);
-  }
+  using Kern = void (*)(OpacityParams);
+  static const Kern kern[2][3] = {{k_opacity8<0, false>, k_opacity8<1, false>, k_opacity8<2, false>},
+                                  {k_opacity8<0, true>, k_opacity8<1, true>, k_opacity8<2, true>}};
+  hipLaunchKernelGGL(kern[p.cust.on ? 1 : 0][p.rebin_mode], dim3(grid), dim3(OP_THREADS), 0, s, p);
   return true;
 }
 
@@ -1612,9 +1708,15 @@ constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
 // wave's run time follows its instruction count (see fast_exp); an earlier form that branched on
 // every layer's presence spent a third of its instructions on that bookkeeping.
 // ------------------------------------------------------------------------------------
+// element offsets of a batch column (all 0 for a single call)
+struct TsOfs {
+  size_t opr, col, res;
+};
+
 template <int L, bool SOLAR, int NZMAX, bool COHERENT, bool RESK>
 __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const int bin_local, double *lds,
-                                                 const int gy, const int bz, const int tslot = -1) {
+                                                 const int gy, const int bz, const int tslot = -1,
+                                                 const TsOfs co = TsOfs{0, 0, 0}) {
 #ifdef CLIMA_STAMPS
 #define TSTAMP(k)                                                                                  \
   do {                                                                                             \
@@ -1648,9 +1750,9 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   const bool col_on = c_raw < ng;
   const int c = col_on ? c_raw : ng - 1;
   const double wcol = col_on ? p.wbin[c] : 0.0;  // g-point weight (radiate.f90:122-126)
-  const double *tauL = p.tau + ((size_t)l * ng + c) * nz;
-  const double *w0L = p.w0 + ((size_t)l * ng + c) * nz;
-  const double *gL = p.g + (size_t)l * nz;
+  const double *tauL = p.tau + co.opr + ((size_t)l * ng + c) * nz;
+  const double *w0L = p.w0 + co.opr + ((size_t)l * ng + c) * nz;
+  const double *gL = p.g + co.opr + (size_t)l * nz;
   // layers [a,b) TOA-first; slot t holds layer a + t - pad when t >= pad, a zero-thickness layer otherwise
   const int a = (lane * nz) >> 6, b = ((lane + 1) * nz) >> 6, pad = L - (b - a);
   const bool is_toa = lane == 0, is_sfc = lane == 63;  // b == nz holds for lane 63 only, and its chunk is never empty
@@ -1752,8 +1854,8 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     Rsfc = p.has_hard_surface ? 1.0 - p.emissivity[ll] : 0.0;  // :186-190
     const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64
     // batched shared-opacity IR launches: blockIdx.z selects the temperature column (strides 0 otherwise)
-    const double *Tcol = p.T + (size_t)bz * p.b_T;
-    const double *Tsfc = p.T_surface + (size_t)bz * p.b_Ts;
+    const double *Tcol = p.T + co.col + (size_t)bz * p.b_T;
+    const double *Tsfc = p.T_surface + co.col + (size_t)bz * p.b_Ts;
     // Planck source at the levels (radiate.f90:65-69): the same for the block's g-point columns, so
     // each of the nz+1 values is computed once per block instead of L+1 times per lane of every wave
     double *sB = lds + (size_t)3 * TSW_COLS * nl;
@@ -1926,7 +2028,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       fd = fd + lds[(size_t)(1 * TSW_COLS + w) * nl + n];
       am = am + lds[(size_t)(2 * TSW_COLS + w) * nl + n];
     }
-    const size_t o = (size_t)ll * nl + (nz - n);
+    const size_t o = co.res + (size_t)ll * nl + (nz - n);
     if (solar) {
       fu = fu * scale * p.diurnal_fac;
       fd = fd * scale * p.diurnal_fac;
@@ -1942,8 +2044,8 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     }
   }
   if (gy == 0 && p.col_base == 0 && p.b_out == 0) {
-    double *tb = solar ? p.sol_tau_band : p.ir_tau_band;
-    for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = ld_opr<COHERENT>(&p.tau_band[(size_t)l * nz + (nz - 1 - i)]);
+    double *tb = (solar ? p.sol_tau_band : p.ir_tau_band) + co.res;
+    for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = ld_opr<COHERENT>(&p.tau_band[co.opr + (size_t)l * nz + (nz - 1 - i)]);
   }
   TSTAMP(8);
 #undef TSTAMP
@@ -2316,38 +2418,56 @@ bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
-// k_fused: opacity and two-stream work of one call in ONE grid.  Blocks [0, n_op) are the
-// opacity blocks of k_opacity8; the blocks after them are the two-stream blocks of
-// k_twostream_w (solar bins first), each of which first waits until the opacity blocks that
-// cover its bin have published their results.  The opacity launch holds two waves per SIMD and
-// its second residency round is half empty; here the two-stream blocks move into those slots
-// as soon as they free up instead of waiting for the whole launch to drain.
-// Forward progress: blocks are dispatched in index order, so whatever a two-stream block waits
-// for is already running or done, and opacity blocks wait for nothing.  The wait is bounded
-// all the same: on expiry the block reports through the error flag and returns.
-// ------------------------------------------------------------------------------------
 #ifndef FUSED_NZMAX
 #define FUSED_NZMAX 8
 #endif
-template <bool MULTI, bool CUSTOM>
+// k_fused: opacity and two-stream work of one call -- or of a batch of columns -- in ONE grid, one
+// workgroup per work item.  The items of column c are the blocks [c*(n_op+n_ts), (c+1)*(n_op+n_ts)):
+// first its n_op opacity tiles, then its n_ts two-stream items (one per (bin, g-point group), ordered
+// by readiness), each of which first waits until the opacity tiles that cover its bin have
+// published.  The opacity code holds two waves per SIMD and its second residency round is half
+// empty; here the two-stream blocks move into those slots as soon as they free up instead of
+// waiting for the whole launch to drain -- and in a batch, one column's two-stream tail runs beside
+// the next column's opacity tiles.
+// Forward progress: workgroups are dispatched in index order (a property of this hardware's
+// dispatcher, not of the programming model: DESIGN.md records it as a dependency), so whatever a
+// two-stream block waits for is already running or done, and opacity tiles wait for nothing.  The
+// wait is bounded all the same: on expiry the block stamps the timeout word and returns, and the
+// host computes the call again through the separate launches.
+// (A persistent form -- two blocks per CU taking items off a queue, which needs no dispatch-order
+// assumption and no workgroup launch per ~10 us two-stream item -- was built and measured: with both
+// bodies inlined into the item loop hipcc spilled 220-470 registers; with the bodies outlined as
+// functions every access went through generic-address-space pointers (flat loads, no scalar loads)
+// and the call took 178 us instead of 104.)
+// LSEL = 0: the two-stream part carries the 2-, 3- and 4-slot forms (fp.slots selects); LSEL = 5..8:
+// that one slot count (columns of 257-512 layers), a kernel of its own so that its register needs do
+// not disturb the allocation of the others.
+template <int RM, bool CUSTOM, int LSEL>
 __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoStreamParams ts, FusedParams fp) {
   extern __shared__ __align__(16) double lds[];
-  if ((int)blockIdx.x < fp.n_op) {
-    opacity8_body<MULTI, CUSTOM, true>(op, (int)blockIdx.x);
+  const int per_col = fp.n_op + fp.n_ts;
+  const int cb = (int)blockIdx.x / per_col, loc = (int)blockIdx.x - cb * per_col;
+  if (loc < fp.n_op) {
+    // ---- an opacity tile of column cb
+    const size_t oc = (size_t)cb * fp.bs.col;
+    if ((long)loc * OP_THREADS < (long)op.nbins * op.col.meta[2 * oc])  // tiles past the compacted lane range are empty
+      opacity8_body<RM, CUSTOM, true>(op, loc, oc, (size_t)cb * fp.bs.prep, (size_t)cb * fp.bs.opr);
     // the opr stores above went out at device scope (write-through); wait until they are
     // acknowledged, then let every wave of the block arrive before the flag goes up
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&fp.done[blockIdx.x], fp.call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0)
+      __hip_atomic_store(&fp.done[(size_t)cb * fp.bs.done + loc], fp.call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  const int b = (int)blockIdx.x - fp.n_op;
+  // ---- a two-stream item of column cb
+  const int b = loc - fp.n_op;
   int gy, bl;
   {
     // Dispatch order of the two-stream blocks = block index order, so the index is mapped to work by
     // readiness: first the solar bins whose opacities come out of the first residency round of
-    // opacity blocks (both g-point groups), then the IR bins (all of them are in that round or
+    // opacity tiles (both g-point groups), then the IR bins (all of them are in that round or
     // early in the second), last the solar bins of the second round.  A block whose opacities are
     // not out yet holds its slot while it waits; in plain (group, channel, bin) order the late solar
     // bins of group 0 sat in front of ready IR work (-0.8 us per call).
@@ -2363,15 +2483,17 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   const int l = (solar ? ts.sol_start : ts.ir_start) + ll;
   __shared__ int s_ok;
 #ifdef CLIMA_STAMPS
-  if (op.stamps && threadIdx.x == 0) op.stamps[64 + 2 * 3128 + 3 * b] = __builtin_amdgcn_s_memrealtime();
+  if (op.stamps && threadIdx.x == 0 && cb == 0) op.stamps[64 + 2 * 3128 + 3 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
   if (threadIdx.x == 0) {
-    const long t0 = (long)(l - op.bin_lo) * op.nz;
-    const int d0 = max((int)(t0 / OP_THREADS), 0), d1 = min((int)((t0 + op.nz - 1) / OP_THREADS), fp.n_op - 1);
+    const int nsrc = op.col.meta[2 * (size_t)cb * fp.bs.col];
+    const long t0 = (long)(l - op.bin_lo) * nsrc;
+    const int d0 = max((int)(t0 / OP_THREADS), 0), d1 = min((int)((t0 + nsrc - 1) / OP_THREADS), fp.n_op - 1);
+    const int *done = fp.done + (size_t)cb * fp.bs.done;
     int ok = 1;
     for (int d = d0; d <= d1 && ok; d++) {
       int spins = 0;
-      while (__hip_atomic_load(&fp.done[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fp.call_id) {
+      while (__hip_atomic_load(&done[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fp.call_id) {
         __builtin_amdgcn_s_sleep(16);
         if (++spins > fp.max_spins) { ok = 0; break; }
       }
@@ -2382,81 +2504,101 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   __syncthreads();
   if (!s_ok) return;
 #ifdef CLIMA_STAMPS
-  if (op.stamps && threadIdx.x == 0) op.stamps[64 + 2 * 3128 + 3 * b + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef CLIMA_STAMPS
-  const int tslot = (b == 1500) ? 32 : (b == 2200 ? 48 : -1);  // a solar and an IR block of the two-stream-only tail
+  if (op.stamps && threadIdx.x == 0 && cb == 0) op.stamps[64 + 2 * 3128 + 3 * b + 1] = __builtin_amdgcn_s_memrealtime();
+  const int tslot = (b == 1500) ? 32 : (b == 2200 ? 48 : -1);  // two blocks of the two-stream-only tail
 #else
   const int tslot = -1;
 #endif
+  const TsOfs co{(size_t)cb * fp.bs.opr, (size_t)cb * fp.bs.col, (size_t)cb * fp.bs.res};
   // The number of slots per lane follows the column height (65-128 layers: 2, up to 192: 3, up to
-  // 256: 4).  Columns of at most 64 layers are not fused at all (fused_supported): their opacity
-  // blocks do not fill the machine once, so there is no half-empty second round to fill, and the
-  // stand-alone one-slot two-stream kernel runs at five waves per SIMD instead of two.  (A fourth
-  // variant in this kernel made hipcc spill 800 bytes per lane: 190 us instead of 116.)
-  if (fp.slots == 2) {
-    if (solar) twostream_p_body<2, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot);
-    else twostream_p_body<2, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
-  } else if (fp.slots == 3) {
-    if (solar) twostream_p_body<3, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot);
-    else twostream_p_body<3, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
+  // 256: 4; 5-8 in the LSEL kernels).  Columns of at most 64 layers are not fused at all
+  // (fused_supported): their opacity tiles do not fill the machine once, so there is no half-empty
+  // second round to fill, and the stand-alone one-slot two-stream kernel runs at five waves per SIMD
+  // instead of two.
+  if constexpr (LSEL == 0) {
+    if (fp.slots == 2) {
+      if (solar) twostream_p_body<2, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot, co);
+      else twostream_p_body<2, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
+    } else if (fp.slots == 3) {
+      if (solar) twostream_p_body<3, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot, co);
+      else twostream_p_body<3, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
+    } else {
+      if (solar) twostream_p_body<4, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot, co);
+      else twostream_p_body<4, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
+    }
   } else {
-    if (solar) twostream_p_body<4, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot);
-    else twostream_p_body<4, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot);
+    if (solar) twostream_p_body<LSEL, true, FUSED_NZMAX, true, false>(ts, bl, lds, gy, 0, tslot, co);
+    else twostream_p_body<LSEL, false, 0, true, false>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
   }
 #ifdef CLIMA_STAMPS
   __syncthreads();
-  if (op.stamps && threadIdx.x == 0) op.stamps[64 + 2 * 3128 + 3 * b + 2] = __builtin_amdgcn_s_memrealtime();
+  if (op.stamps && threadIdx.x == 0 && cb == 0) op.stamps[64 + 2 * 3128 + 3 * b + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
 // false when the configuration is outside what the fused form covers (the caller then uses the
 // separate launches)
 bool fused_supported(const OpacityParams &op, const TwoStreamParams &ts) {
-  if (op.ng != 8 || (ts.nz + 63) / 64 > 4 || (ts.nz + 63) / 64 < 2 || ts.nzen > MAX_ZEN) return false;
+  const int slots = (ts.nz + 63) / 64;
+  if (op.ng != 8 || slots < 2 || slots > 8 || ts.nzen > MAX_ZEN) return false;
+  if (slots > 4 && (op.rebin_mode != 0 || op.cust.on)) return false;  // the 5-8 slot kernels exist for the default form only
   return (long)op.nbins * op.nz > 0 && ts.n_sol + ts.n_ir > 0;
 }
 
+int fused_tiles(const OpacityParams &op) {
+  return (int)(((long)op.nbins * op.nsrc + OP_THREADS - 1) / OP_THREADS);
+}
+
+using FusedKern = void (*)(OpacityParams, TwoStreamParams, FusedParams);
+static FusedKern fused_kernel(const OpacityParams &op, int slots) {
+  static const FusedKern k04[2][3] = {{k_fused<0, false, 0>, k_fused<1, false, 0>, k_fused<2, false, 0>},
+                                      {k_fused<0, true, 0>, k_fused<1, true, 0>, k_fused<2, true, 0>}};
+  static const FusedKern k58[4] = {k_fused<0, false, 5>, k_fused<0, false, 6>, k_fused<0, false, 7>, k_fused<0, false, 8>};
+  return slots <= 4 ? k04[op.cust.on ? 1 : 0][op.rebin_mode] : k58[slots - 5];
+}
+
+// fp.ncol, fp.bs, fp.call_id, fp.max_spins, fp.done, fp.timeout_flag come from the caller.
+// op.nsrc = source layers per column (nz for a batch, where the tile count is an upper bound).
 bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s) {
   if (!fused_supported(op, ts)) return false;
-  const long total = (long)op.nbins * op.nz;
   const int nb = ts.n_sol + ts.n_ir;
-  fp.n_op = (int)((total + OP_THREADS - 1) / OP_THREADS);
-  fp.slots = (ts.nz + 63) / 64;  // 2..4 (fused_supported)
+  const int groups = (ts.ng + TSW_COLS - 1) / TSW_COLS;  // 2
+  fp.n_op = fused_tiles(op);
+  fp.n_ts = nb * groups;
+  fp.slots = (ts.nz + 63) / 64;  // 2..8 (fused_supported)
+  if (fp.ncol < 1) fp.ncol = 1;
   {
-    // solar bins (of this shard) whose opacity blocks sit in the first residency round: two blocks per CU
-    const int cus = device_cus();
-    const long first_round_bins = ((long)2 * cus * OP_THREADS) / op.nz;
+    // solar bins (of this shard) whose opacity tiles sit in the first residency round: two blocks per CU
+    const long first_round_bins = ((long)2 * device_cus() * OP_THREADS) / std::max(op.nsrc, 1);
     fp.sol_early = (int)std::min<long>(ts.n_sol, std::max<long>(0, first_round_bins - (long)(ts.sol_start + ts.sol_lo - op.bin_lo)));
   }
-  const int groups = (ts.ng + TSW_COLS - 1) / TSW_COLS;  // 2
   ts.col_base = 0; ts.accumulate = 1;
   const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)ts.nz + 1);
-  const dim3 grid(fp.n_op + nb * groups), blk(OP_THREADS);
-  if (op.cust.on) {
-    if (op.multi_edge) hipLaunchKernelGGL((k_fused<true, true>), grid, blk, lds, s, op, ts, fp);
-    else hipLaunchKernelGGL((k_fused<false, true>), grid, blk, lds, s, op, ts, fp);
-  } else {
-    if (op.multi_edge) hipLaunchKernelGGL((k_fused<true, false>), grid, blk, lds, s, op, ts, fp);
-    else hipLaunchKernelGGL((k_fused<false, false>), grid, blk, lds, s, op, ts, fp);
-  }
+  const long items = (long)fp.ncol * (fp.n_op + fp.n_ts);
+  const FusedKern k = fused_kernel(op, fp.slots);
+  if (lds > 48 * 1024 && !ensure_max_lds((const void *)k, 64 * 1024)) return false;  // (the kernel has static LDS too)
+  hipLaunchKernelGGL(k, dim3((unsigned)items), dim3(OP_THREADS), lds, s, op, ts, fp);
   return true;
 }
 
-bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, hipStream_t s) {
-  if (ts.ng != 8 || slots < 2 || slots > 4 || (ts.nz + 63) / 64 > slots || ts.nzen > MAX_ZEN) return false;
+bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s) {
+  if (ts.ng != 8 || slots < 2 || slots > 8 || (ts.nz + 63) / 64 > slots || ts.nzen > MAX_ZEN) return false;
   OpacityParams op;
   memset(&op, 0, sizeof(op));
   op.nz = ts.nz;
+  op.col.meta = meta_nsrc;   // one int: the two-stream blocks read the column's source-layer count
   FusedParams fp;
   memset(&fp, 0, sizeof(fp));
-  fp.n_op = 0;        // no opacity blocks: the two-stream blocks have nothing to wait for
+  fp.ncol = 1;
+  fp.n_op = 0;        // no opacity tiles: the two-stream blocks have nothing to wait for
+  fp.n_ts = (ts.n_sol + ts.n_ir) * ((ts.ng + TSW_COLS - 1) / TSW_COLS);
   fp.slots = slots;
   fp.sol_early = ts.n_sol;
   ts.col_base = 0; ts.accumulate = 1;
-  const int groups = (ts.ng + TSW_COLS - 1) / TSW_COLS;
   const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)ts.nz + 1);
-  hipLaunchKernelGGL((k_fused<false, false>), dim3((ts.n_sol + ts.n_ir) * groups), dim3(OP_THREADS), lds, s, op, ts, fp);
+  const FusedKern k = fused_kernel(op, slots);
+  if (lds > 48 * 1024 && !ensure_max_lds((const void *)k, 64 * 1024)) return false;
+  hipLaunchKernelGGL(k, dim3(fp.n_ts), dim3(OP_THREADS), lds, s, op, ts, fp);
   return true;
 }
 
@@ -2583,7 +2725,9 @@ __global__ __launch_bounds__(INT_LV * INT_CG) void k_integrate_one(IntegratePara
     if (p.flux_part && cg == 0 && i < nl) p.flux_n[a * nl + i] = p.flux_part[a * nl + i];
     return;
   }
-  const double *src = a == 0 ? p.ir_fup_a : a == 1 ? p.ir_fdn_a : a == 2 ? p.sol_fup_a : p.sol_fdn_a;
+  const int cb = blockIdx.z;  // column of a batch
+  const double *src = (a == 0 ? p.ir_fup_a : a == 1 ? p.ir_fdn_a : a == 2 ? p.sol_fup_a : p.sol_fdn_a) + (size_t)cb * p.bs.res;
+  double *const flux_n = p.flux_n + (size_t)cb * p.bs.flux;
   const double *freq = sol ? p.sol_freq : p.ir_freq;
   const int lo = sol ? p.sol_lo : p.ir_lo, cnt = sol ? p.sol_n : p.ir_n;
   double *s_df = s_int;
@@ -2616,7 +2760,7 @@ __global__ __launch_bounds__(INT_LV * INT_CG) void k_integrate_one(IntegratePara
   if (cg == 0 && i < nl) {
     double acc = 0.0;
     for (int k = 0; k < p.nchunk; k++) acc = acc + s_part[k * INT_LV + lv];
-    p.flux_n[a * nl + i] = acc;
+    flux_n[a * nl + i] = acc;
     if (p.flux_part) p.flux_part[a * nl + i] = acc;
   }
 }
@@ -2625,7 +2769,7 @@ void launch_integrate(const IntegrateParams &p, hipStream_t s) {
   const int nl = p.nz + 1;
   const size_t lds = sizeof(double) * (size_t)p.nchunk * (INT_CHUNK + INT_LV);
   if (lds <= 64 * 1024) {
-    hipLaunchKernelGGL(k_integrate_one, dim3((nl + INT_LV - 1) / INT_LV, 4), dim3(INT_LV * INT_CG), lds, s, p);
+    hipLaunchKernelGGL(k_integrate_one, dim3((nl + INT_LV - 1) / INT_LV, 4, p.ncol > 0 ? p.ncol : 1), dim3(INT_LV * INT_CG), lds, s, p);
     return;
   }
   hipLaunchKernelGGL(k_integrate_partial, dim3(p.nchunk, 4), dim3(256), 0, s, p);

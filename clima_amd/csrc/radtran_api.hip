@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <set>
 #include <string>
 #include <utility>
@@ -141,10 +142,13 @@ struct Radtran {
   DevBuf<double> d_cust_axis, d_cust_dtau, d_cust_w0, d_cust_g0;
   // batched shared-opacity IR calls (radtran_radiate_ir_batch)
   DevBuf<double> d_bT, d_bTs, d_bup, d_bdn, d_bpartial, d_bout;
-  DevBuf<double> d_col;  // [T_surface | T | P | dz | dens | pdens | radii]
-  DevBuf<double> d_log10P, d_cols, d_foreign, d_q, d_absw;
+  DevBuf<double> d_col;  // [T_surface | T | P | dz | dens | pdens | radii | meta (ints: nsrc, source list, source of every layer)]
+  size_t meta_ofs = 0;   // doubles before the meta ints in a column block
+  int nsrc = 0;          // source layers of the resident column (pair_reuse decided at upload)
+  DevBuf<double> d_prep;  // one block: [log10P | cols | foreign_col | absw | q | ix (ints)]
+  size_t prep_count = 0;
   std::vector<AbsEntry> abs_entries;  // continuum terms in the reference's summation order
-  DevBuf<int> d_src, d_ix, d_err;
+  DevBuf<int> d_err;
 #ifdef CLIMA_STAMPS
   DevBuf<long long> d_stamps;
 #endif
@@ -161,7 +165,9 @@ struct Radtran {
   int fused_max_spins = 400000, checked_timeout = 0, solar_id = 0, fused_fallbacks = 0;
   bool last_cs = true;
   std::vector<double> last_T, last_P, last_radii;  // host copy for byte accounting
-  // opr
+  // opr: one block [tau | w0 | g | tau_band]; the four are views into it
+  DevBuf<double> d_opr;
+  size_t opr_count = 0;
   DevBuf<double> d_tau, d_w0, d_g, d_tau_band;
   bool opr_valid = false;
   // results
@@ -179,8 +185,13 @@ struct Radtran {
   hipStream_t stream = nullptr;
   // column batches (radtran_toa_fluxes_batch): the column / level-flux buffers a call works on
   double *col_override = nullptr, *flux_override = nullptr, *ftot_override = nullptr;
+  int nsrc_override = 0;
   DevBuf<double> d_cols_arena, d_flux_arena;
+  // one-launch batches: per-column prep / opr / spectra blocks for the columns in flight
+  DevBuf<double> d_prep_arena, d_opr_arena, d_res_arena;
+  int batch_cols_in_flight = 64;
   bool batch_shared = true;        // radiate_ir_batch: temperature-independent work shared by the columns (CLIMA_HIP_BATCH_SHARED=0: one full solve per column)
+  int rebin_mode = 1;              // 0 window form, 1 streaming, 2 streaming multi-edge (rebin_mode_for)
   bool fused = true;               // opacity + two-stream in one grid (k_fused); CLIMA_HIP_FUSED=0 or radtran_fused_set turns it off
   DevBuf<int> d_done;              // per opacity block: call id of its last completed run
   int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (id 1) only
@@ -292,6 +303,50 @@ void upload_fields(Radtran *r) {
   r->fields_dirty = false;
 }
 
+// Which rebin form the opacity kernels may use for these g-point weights (ng = 8).  The window form
+// evaluates, for output edge k, only the sorted elements [RB_WIN_LO[k], RB_WIN_HI[k]]; the element j*
+// that crosses E_k (C_{j*-1} < E_k <= C_{j*}) must be among them WHATEVER order the sort produces.
+// C_j is bounded by the sums of the j+1 smallest / largest pair weights, so
+//   j* >= first j with (sum of the j+1 largest)  >= E_k,   j* <= first j with (sum of the j+1 smallest) >= E_k.
+// Both bounds are taken with a relative slack far above the rounding of a 64-term sum.
+int rebin_mode_for(const std::vector<double> &wbin, const std::vector<double> &wbin_e, const std::vector<double> &wxy) {
+  const int multi = (*std::max_element(wxy.begin(), wxy.end()) > *std::min_element(wbin.begin(), wbin.end())) ? 2 : 1;
+  if (wbin.size() != 8) return multi;
+  if (const char *e = getenv("CLIMA_HIP_REBIN")) { if (std::strcmp(e, "stream") == 0) return multi; }
+  std::vector<double> s(wxy);
+  std::sort(s.begin(), s.end());
+  if (s[0] <= 0.0) return multi;
+  double lo[64], hi[64], a = 0.0, b = 0.0;
+  for (int j = 0; j < 64; j++) { a += s[j]; b += s[63 - j]; lo[j] = a; hi[j] = b; }
+  for (int k = 1; k < 8; k++) {
+    const double E = wbin_e[k];
+    int jlo = 0, jhi = 0;
+    while (jlo < 63 && hi[jlo] < E * (1.0 - 1e-9)) jlo++;
+    while (jhi < 63 && lo[jhi] < E * (1.0 + 1e-9)) jhi++;
+    if (jlo < RB_WIN_LO[k] || jhi > RB_WIN_HI[k]) return multi;
+  }
+  // the tight table (x and y ascending): lightest / heaviest down-set (Young diagram within the 8x8
+  // grid of pairs (i, j), weight wbin(i)*wbin(j)) of every size, by enumeration of the 12 870 diagrams
+  double dlo[65], dhi[65];
+  for (int n = 0; n <= 64; n++) { dlo[n] = 1e300; dhi[n] = -1.0; }
+  double rowcum[8][9];
+  for (int i = 0; i < 8; i++) { rowcum[i][0] = 0.0; for (int j = 0; j < 8; j++) rowcum[i][j + 1] = rowcum[i][j] + wbin[i] * wbin[j]; }
+  int len[8];
+  std::function<void(int, int, int, double)> rec = [&](int i, int maxlen, int size, double wt) {
+    if (i == 8) { dlo[size] = std::min(dlo[size], wt); dhi[size] = std::max(dhi[size], wt); return; }
+    for (int rl = 0; rl <= maxlen; rl++) { len[i] = rl; rec(i + 1, rl, size + rl, wt + rowcum[i][rl]); }
+  };
+  rec(0, 8, 0, 0.0);
+  for (int k = 1; k < 8; k++) {
+    const double E = wbin_e[k];
+    int jlo = 0, jhi = 0;
+    while (jlo < 63 && dhi[jlo + 1] < E * (1.0 - 1e-9)) jlo++;
+    while (jhi < 63 && dlo[jhi + 1] < E * (1.0 + 1e-9)) jhi++;
+    if (jlo < RB_TIGHT_LO[k] || jhi > RB_TIGHT_HI[k]) return multi;
+  }
+  return 0;
+}
+
 // relative cost of a bin's opacity work, IR solve, solar solve (base + per zenith angle)
 constexpr double SHARD_W_OP = 3.0, SHARD_W_IR = 1.0, SHARD_W_SOL0 = 0.6, SHARD_W_SOLZ = 0.24;
 
@@ -375,26 +430,83 @@ void resolve_events(Radtran *r) {
   r->pending.clear();
 }
 
-ColumnDev column_dev(Radtran *r) {
+// Prep block of one column (d_prep or a slice of the batch arena)
+void prep_views(Radtran *r, double *base, ColumnDev &c) {
+  const size_t nz = r->nz, nab = std::max<size_t>(1, r->abs_entries.size()), ns = (size_t)r->nslots + 1;
+  c.log10P = base;
+  c.cols = c.log10P + nz;
+  c.foreign_col = c.cols + nz * r->nsp;
+  c.absw = c.foreign_col + nz;
+  c.q = c.absw + nab * nz;
+  c.ix = reinterpret_cast<int *>(c.q + ns * nz);
+}
+size_t prep_block_count(Radtran *r) {
+  const size_t nz = r->nz, nab = std::max<size_t>(1, r->abs_entries.size()), ns = (size_t)r->nslots + 1;
+  return nz * (2 + r->nsp + nab + ns) + (ns * nz + 1) / 2;
+}
+
+ColumnDev column_dev_at(Radtran *r, double *col_base, double *prep_base) {
   ColumnDev c;
   const int nz = r->nz;
-  double *base = r->col_override ? r->col_override : r->d_col.p;
-  c.T_surface = base;
-  c.T = base + 1;
+  c.T_surface = col_base;
+  c.T = col_base + 1;
   c.P = c.T + nz;
   c.dz = c.P + nz;
   c.dens = c.dz + nz;
   c.pdens = c.dens + (size_t)r->nsp * nz;
   c.radii = c.pdens + (size_t)r->np * nz;
-  c.log10P = r->d_log10P.p;
-  c.cols = r->d_cols.p;
-  c.foreign_col = r->d_foreign.p;
-  c.absw = r->d_absw.p;
-  c.src = r->d_src.p;
-  c.ix = r->d_ix.p;
-  c.q = r->d_q.p;
+  c.meta = reinterpret_cast<const int *>(col_base + r->meta_ofs);
+  prep_views(r, prep_base, c);
   c.err_flag = r->d_err.p;
   return c;
+}
+
+ColumnDev column_dev(Radtran *r) {
+  return column_dev_at(r, r->col_override ? r->col_override : r->d_col.p, r->d_prep.p);
+}
+
+// pair_reuse (clima_radtran_types.f90:621-632), decided here once per column so that the grid size
+// and every kernel work from ONE definition: for even nz, layer j (1-based even) reuses layer j-1
+// when P, T, every column densities*dz and (with particles) every radius agree to 1e-12 (is_close).
+// meta: [0] = nsrc, [1 + m] = m-th source layer (0-based, ascending) | SRC_PAIR | SRC_EXACT,
+// [1 + nz + j] = source layer of layer j.  Returns nsrc.
+int build_meta(Radtran *r, const double *T, const double *P, const double *dz, const double *dens,
+               const double *pdens, const double *radii, bool has_particles, int *meta) {
+#pragma clang fp contract(off)  // the columns are stored products in the reference (opw%cols), never fused into the comparison
+  const int nz = r->nz, nsp = r->nsp, np = r->np;
+  const double tol = 1.0e-12;
+  const bool use_radii = has_particles && radii && !r->part.empty();  // present(radii) .and. self%npart > 0
+  int nsrc = 0;
+  int *srcl = meta + 1, *src = meta + 1 + nz;
+  for (int j = 0; j < nz; j++) {
+    bool reuse = false, exact = false;
+    if ((nz & 1) == 0 && (j & 1) == 1) {
+      reuse = is_close(P[j], P[j - 1], tol) && is_close(T[j], T[j - 1], tol);
+      exact = P[j] == P[j - 1] && T[j] == T[j - 1] && dz[j] == dz[j - 1];
+      for (int i = 0; i < nsp && reuse; i++) {
+        const volatile double ca = dens[(size_t)i * nz + j] * dz[j], cb = dens[(size_t)i * nz + j - 1] * dz[j - 1];  // opw%cols
+        reuse = is_close(ca, cb, tol);
+        exact = exact && dens[(size_t)i * nz + j] == dens[(size_t)i * nz + j - 1];
+      }
+      if (use_radii)
+        for (int i = 0; i < np && reuse; i++) reuse = is_close(radii[(size_t)i * nz + j], radii[(size_t)i * nz + j - 1], tol);
+      if (reuse && np > 0 && has_particles && pdens && radii)
+        for (int i = 0; i < np; i++)
+          exact = exact && pdens[(size_t)i * nz + j] == pdens[(size_t)i * nz + j - 1] &&
+                  radii[(size_t)i * nz + j] == radii[(size_t)i * nz + j - 1];
+      exact = exact && reuse;
+    }
+    if (reuse) {
+      srcl[nsrc - 1] |= SRC_PAIR | (exact ? SRC_EXACT : 0);  // layer j-1 is the entry just written
+      src[j] = j - 1;
+    } else {
+      srcl[nsrc++] = j;
+      src[j] = j;
+    }
+  }
+  for (int m = nsrc; m < nz; m++) srcl[m] = nz - 1;
+  meta[0] = nsrc;
+  return nsrc;
 }
 
 TwoStreamParams make_twostream_params(Radtran *r, const ColumnDev &col, bool compute_solar) {
@@ -423,18 +535,57 @@ TwoStreamParams make_twostream_params(Radtran *r, const ColumnDev &col, bool com
   return ts;
 }
 
-void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool allow_fused = true) {
+// A batch of columns worked on by ONE launch of each kernel (radtran_toa_fluxes_batch): per-column
+// blocks in arenas, column c at base + c * stride.  Null for a single call on the handle's own buffers.
+struct BatchCtx {
+  int ncol;
+  double *col, *prep, *opr, *res, *flux;
+  int *done;
+  BatchStrides bs;
+};
+
+// spectra block of one column of a batch: [ir fup_a | ir fdn_a | ir tau_band | sol fup_a | sol fdn_a | sol amean | sol tau_band]
+size_t res_block_count(Radtran *r) {
+  const size_t nl = (size_t)r->nz + 1, nz = r->nz;
+  return (size_t)r->ir.nw * (2 * nl + nz) + (size_t)r->sol.nw * (3 * nl + nz);
+}
+
+void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool allow_fused = true,
+                     const BatchCtx *bc = nullptr) {
   r->timer_calls++;
   upload_fields(r);
   const int nz = r->nz;
-  ColumnDev col = column_dev(r);
+  const size_t nl = (size_t)nz + 1;
+  ColumnDev col = bc ? column_dev_at(r, bc->col, bc->prep) : column_dev(r);
+  BatchStrides bs;
+  std::memset(&bs, 0, sizeof(bs));
+  if (bc) bs = bc->bs;
+  const int ncol = bc ? bc->ncol : 1;
+  const int nsrc = bc ? nz : (r->col_override ? r->nsrc_override : r->nsrc);
+  // where this call's optical properties and spectra live
+  double *o_tau = r->d_tau.p, *o_w0 = r->d_w0.p, *o_g = r->d_g.p, *o_tb = r->d_tau_band.p;
+  double *ir_fup = r->wrk_ir.fup_a.p, *ir_fdn = r->wrk_ir.fdn_a.p, *ir_tb = r->wrk_ir.tau_band.p;
+  double *sol_fup = r->wrk_sol.fup_a.p, *sol_fdn = r->wrk_sol.fdn_a.p, *sol_am = r->wrk_sol.amean.p, *sol_tb = r->wrk_sol.tau_band.p;
+  if (bc) {
+    o_tau = bc->opr; o_w0 = o_tau + r->d_tau.n; o_g = o_w0 + r->d_w0.n; o_tb = o_g + r->d_g.n;
+    ir_fup = bc->res; ir_fdn = ir_fup + r->ir.nw * nl; ir_tb = ir_fdn + r->ir.nw * nl;
+    sol_fup = ir_tb + (size_t)r->ir.nw * nz; sol_fdn = sol_fup + r->sol.nw * nl; sol_am = sol_fdn + r->sol.nw * nl;
+    sol_tb = sol_am + r->sol.nw * nl;
+  }
+  auto ts_params = [&]() {
+    TwoStreamParams ts = make_twostream_params(r, col, compute_solar);
+    ts.tau = o_tau; ts.w0 = o_w0; ts.g = o_g; ts.tau_band = o_tb;
+    ts.ir_fup_a = ir_fup; ts.ir_fdn_a = ir_fdn; ts.ir_tau_band = ir_tb;
+    ts.sol_fup_a = sol_fup; ts.sol_fdn_a = sol_fdn; ts.sol_amean = sol_am; ts.sol_tau_band = sol_tb;
+    return ts;
+  };
   bool pre_zeroed = false, fused_done = false;
   if (compute_opacity) {
     PrepParams pp;
     std::memset(&pp, 0, sizeof(pp));
+    pp.ncol = ncol; pp.bs = bs;
     pp.nz = nz; pp.nsp = r->nsp; pp.np = r->np; pp.nslots = r->nslots;
     pp.has_cont = r->has_cont; pp.LH2O = r->LH2O;
-    pp.check_radii = (r->column_has_particles && !r->part.empty()) ? 1 : 0;  // types.f90:628
     for (int s = 0; s < r->nslots; s++) pp.slots[s] = r->slots[s];
     if (r->cust_on) {  // evaluated without clamping: the end intervals extrapolate (linear_interpolation_module.F90:348-350)
       SlotDev cs;
@@ -453,16 +604,15 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
       const bool wave_mode = !(mode && std::strcmp(mode, "block") == 0) && (nz + 63) / 64 <= 8;
       pre_zeroed = false;
       if (wave_mode && twostream_w_groups(r->ng) >= 2) {
-        const size_t nl = (size_t)nz + 1;
         int n = 0;
         if (r->ir_n > 0) {
-          pp.zero_ptr[n] = r->wrk_ir.fup_a.p + (size_t)r->ir_lo * nl; pp.zero_count[n++] = nl * r->ir_n;
-          pp.zero_ptr[n] = r->wrk_ir.fdn_a.p + (size_t)r->ir_lo * nl; pp.zero_count[n++] = nl * r->ir_n;
+          pp.zero_ptr[n] = ir_fup + (size_t)r->ir_lo * nl; pp.zero_count[n++] = nl * r->ir_n;
+          pp.zero_ptr[n] = ir_fdn + (size_t)r->ir_lo * nl; pp.zero_count[n++] = nl * r->ir_n;
         }
         if (compute_solar && r->sol_n > 0) {
-          pp.zero_ptr[n] = r->wrk_sol.fup_a.p + (size_t)r->sol_lo * nl; pp.zero_count[n++] = nl * r->sol_n;
-          pp.zero_ptr[n] = r->wrk_sol.fdn_a.p + (size_t)r->sol_lo * nl; pp.zero_count[n++] = nl * r->sol_n;
-          pp.zero_ptr[n] = r->wrk_sol.amean.p + (size_t)r->sol_lo * nl; pp.zero_count[n++] = nl * r->sol_n;
+          pp.zero_ptr[n] = sol_fup + (size_t)r->sol_lo * nl; pp.zero_count[n++] = nl * r->sol_n;
+          pp.zero_ptr[n] = sol_fdn + (size_t)r->sol_lo * nl; pp.zero_count[n++] = nl * r->sol_n;
+          pp.zero_ptr[n] = sol_am + (size_t)r->sol_lo * nl; pp.zero_count[n++] = nl * r->sol_n;
         }
         pp.nzero = n;
         pre_zeroed = true;
@@ -473,7 +623,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     OpacityParams op;
     std::memset(&op, 0, sizeof(op));
     op.nz = nz; op.nw = r->nw; op.ng = r->ng; op.nsp = r->nsp; op.np = r->np;
-    op.bin_lo = r->op_lo; op.nbins = r->op_n;
+    op.bin_lo = r->op_lo; op.nbins = r->op_n; op.nsrc = nsrc;
     op.nk = (int)r->k.size(); op.nray = (int)r->ray.size(); op.npart = (int)r->part.size();
     for (size_t i = 0; i < r->k.size(); i++)
       op.k[i] = KDev{r->k[i]->d_log10k.p, r->k[i]->sp, r->k[i]->nP, r->k[i]->nT, (int)(2 * i), (int)(2 * i + 1)};
@@ -485,21 +635,26 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     op.wbin = r->d_wbin.p; op.wbin_e = r->d_wbin_e.p; op.wxy = r->d_wxy.p; op.wbin_e_pad = r->d_wbin_e_pad.p;
     op.col = col;
     op.cust = CustomDev{r->d_cust_dtau.p, r->d_cust_w0.p, r->d_cust_g0.p, r->cust_nP, r->nslots, r->cust_on ? 1 : 0};
-    op.multi_edge = (*std::max_element(r->wxy.begin(), r->wxy.end()) > *std::min_element(r->wbin.begin(), r->wbin.end())) ? 1 : 0;
+    op.rebin_mode = r->rebin_mode;
 #ifdef CLIMA_STAMPS
     op.stamps = r->d_stamps.p;
 #endif
-    op.tau = r->d_tau.p; op.w0 = r->d_w0.p; op.g = r->d_g.p; op.tau_band = r->d_tau_band.p;
-    if (r->fused && allow_fused && pre_zeroed) {
-      TwoStreamParams tsf = make_twostream_params(r, col, compute_solar);
-      if (fused_supported(op, tsf)) {
-        FusedParams fp{0, pp.call_id, r->fused_max_spins, r->d_done.p, r->d_err.p + 1, 0, 0};
+    op.tau = o_tau; op.w0 = o_w0; op.g = o_g; op.tau_band = o_tb;
+    if (bc || (r->fused && allow_fused && pre_zeroed)) {
+      TwoStreamParams tsf = ts_params();
+      if (fused_supported(op, tsf) && pre_zeroed) {
+        FusedParams fp;
+        std::memset(&fp, 0, sizeof(fp));
+        fp.ncol = ncol; fp.bs = bs;
+        fp.call_id = pp.call_id; fp.max_spins = r->fused_max_spins;
+        fp.done = bc ? bc->done : r->d_done.p; fp.timeout_flag = r->d_err.p + 1;
         KernelTimer t(r, 1);
         fused_done = launch_fused(op, tsf, fp, r->stream);
         HIPCHK(hipGetLastError());
         t.stop();
       }
     }
+    if (bc && !fused_done) throw HipFail{"internal: a one-launch batch needs the fused grid"};
     if (!fused_done) {
       KernelTimer t(r, 1);
       const bool ok = launch_opacity(op, r->stream);
@@ -513,7 +668,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
   r->last_cs = compute_solar;
   if (compute_solar) r->solar_id = r->call_id;
 
-  TwoStreamParams ts = make_twostream_params(r, col, compute_solar);
+  TwoStreamParams ts = ts_params();
   if (!fused_done) {
     KernelTimer t(r, 2);
     // default: wave-per-column kernel; CLIMA_HIP_TS_MODE=block selects the workgroup-per-bin form
@@ -529,13 +684,14 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
 
   IntegrateParams ip;
   std::memset(&ip, 0, sizeof(ip));
+  ip.ncol = ncol; ip.bs = bs;
   ip.nz = nz; ip.nw_ir = r->ir.nw; ip.nw_sol = r->sol.nw;
   ip.ir_lo = r->ir_lo; ip.ir_n = r->ir_n; ip.sol_lo = r->sol_lo; ip.sol_n = r->sol_n;
   ip.do_solar = compute_solar ? 1 : 0;
-  ip.ir_fup_a = r->wrk_ir.fup_a.p; ip.ir_fdn_a = r->wrk_ir.fdn_a.p;
-  ip.sol_fup_a = r->wrk_sol.fup_a.p; ip.sol_fdn_a = r->wrk_sol.fdn_a.p;
+  ip.ir_fup_a = ir_fup; ip.ir_fdn_a = ir_fdn;
+  ip.sol_fup_a = sol_fup; ip.sol_fdn_a = sol_fdn;
   ip.ir_freq = r->ir.d_freq.p; ip.sol_freq = r->sol.d_freq.p;
-  ip.flux_n = r->flux_override ? r->flux_override : r->d_flux_n.p;
+  ip.flux_n = bc ? bc->flux : (r->flux_override ? r->flux_override : r->d_flux_n.p);
   ip.flux_part = r->shard_world > 1 ? r->d_flux_part.p : nullptr;
   ip.f_total = r->shard_world == 1 ? (r->ftot_override ? r->ftot_override : r->d_f_total.p) : nullptr;
   ip.nchunk = integrate_chunks(std::max(r->ir_n, r->sol_n));
@@ -595,6 +751,7 @@ void do_upload(Radtran *r, double T_surface, const double *T, const double *P, c
     std::memcpy(hp + (size_t)nz * r->np, radii, sizeof(double) * (size_t)nz * r->np);
   }
   r->column_has_particles = (pdens && radii);
+  r->nsrc = build_meta(r, T, P, dz, dens, pdens, radii, r->column_has_particles, reinterpret_cast<int *>(h + r->meta_ofs));
   {
     // ~18 KB: a kernel that reads the pinned buffer over PCIe gets the column into HBM 4 us sooner
     // than the copy engine does (CLIMA_HIP_COPY_KERNEL=0 selects hipMemcpyAsync)
@@ -703,6 +860,7 @@ void radtran_add_ktable(void *ptr, const int *sp_ind, const int *ngauss, const d
     r->wxy.assign((size_t)r->ng * r->ng, 0.0);
     for (int i = 0; i < r->ng; i++)
       for (int j = 0; j < r->ng; j++) r->wxy[j + (size_t)i * r->ng] = r->wbin[i] * r->wbin[j];
+    r->rebin_mode = rebin_mode_for(r->wbin, r->wbin_e, r->wxy);
   }
   r->k.push_back(k);
 }
@@ -1056,21 +1214,24 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   r->d_am_f1.upload(f1); r->d_am_f2.upload(f2); r->d_am_dw.upload(dw);
 
   // ---- column, prep, opr, results
-  r->col_count = 1 + (size_t)3 * nz + (size_t)nz * r->nsp + (size_t)2 * nz * r->np;
+  r->meta_ofs = 1 + (size_t)3 * nz + (size_t)nz * r->nsp + (size_t)2 * nz * r->np;
+  r->col_count = r->meta_ofs + (size_t)nz + 1;   // + (2 nz + 1) ints
   r->d_col.alloc(r->col_count);
   r->d_col.zero();
   HIPCHK(hipHostMalloc((void **)&r->h_col, sizeof(double) * r->col_count, hipHostMallocMapped));
+  std::memset(r->h_col, 0, sizeof(double) * r->col_count);
   if (hipHostGetDevicePointer((void **)&r->h_col_dev, r->h_col, 0) != hipSuccess) { r->h_col_dev = nullptr; (void)hipGetLastError(); }
-  r->d_log10P.alloc(nz); r->d_cols.alloc((size_t)nz * r->nsp); r->d_foreign.alloc(nz);
-  r->d_absw.alloc((size_t)std::max<size_t>(1, r->abs_entries.size()) * nz);
-  r->d_src.alloc(nz); r->d_ix.alloc((size_t)(r->nslots + 1) * nz); r->d_q.alloc((size_t)(r->nslots + 1) * nz);
+  r->prep_count = prep_block_count(r);
+  r->d_prep.alloc(r->prep_count); r->d_prep.zero();
   r->d_done.alloc(((size_t)nw * nz + 255) / 256 + 1); r->d_done.zero();
+  if (const char *f = getenv("CLIMA_HIP_BATCH_COLS")) r->batch_cols_in_flight = std::max(1, atoi(f));
 #ifdef CLIMA_STAMPS
   r->d_stamps.alloc(64 + 2 * 8192); r->d_stamps.zero();
 #endif
-  r->d_tau.alloc((size_t)nw * ng * nz); r->d_w0.alloc((size_t)nw * ng * nz);
-  r->d_g.alloc((size_t)nw * nz); r->d_tau_band.alloc((size_t)nw * nz);
-  r->d_tau.zero(); r->d_w0.zero(); r->d_g.zero(); r->d_tau_band.zero();
+  r->opr_count = (size_t)2 * nw * ng * nz + (size_t)2 * nw * nz;
+  r->d_opr.alloc(r->opr_count); r->d_opr.zero();
+  r->d_tau.view(r->d_opr.p, (size_t)nw * ng * nz); r->d_w0.view(r->d_tau.p + r->d_tau.n, (size_t)nw * ng * nz);
+  r->d_g.view(r->d_w0.p + r->d_w0.n, (size_t)nw * nz); r->d_tau_band.view(r->d_g.p + r->d_g.n, (size_t)nw * nz);
   auto mk = [&](WrkObj &wk, int which, int nwc) {  // clima_radtran.f90:199-214
     wk.parent = r; wk.which = which;
     wk.fup_a.alloc((size_t)(nz + 1) * nwc); wk.fdn_a.alloc((size_t)(nz + 1) * nwc);
@@ -1206,7 +1367,8 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
   TRY
   const int nz = r->nz, nl = nz + 1, n = *ncol;
   const size_t cc = r->col_count;
-  std::vector<double> h((size_t)n * cc);
+  std::vector<double> h((size_t)n * cc, 0.0);
+  std::vector<int> nsrc_h(n);
   for (int c = 0; c < n; c++) {  // the device layout of one column (do_upload)
     double *d = h.data() + (size_t)c * cc;
     d[0] = T_surface[c];
@@ -1219,6 +1381,8 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
       std::memcpy(dp, pdensities + (size_t)c * nz * r->np, sizeof(double) * (size_t)nz * r->np);
       std::memcpy(dp + (size_t)nz * r->np, radii + (size_t)c * nz * r->np, sizeof(double) * (size_t)nz * r->np);
     }
+    nsrc_h[c] = build_meta(r, d + 1, d + 1 + nz, d + 1 + 2 * nz, d + 1 + 3 * nz, r->np > 0 ? dp : nullptr,
+                           r->np > 0 ? dp + (size_t)nz * r->np : nullptr, r->np > 0, reinterpret_cast<int *>(d + r->meta_ofs));
   }
   if (r->d_cols_arena.n < h.size()) r->d_cols_arena.alloc(h.size());
   if (r->d_flux_arena.n < (size_t)n * 5 * nl) r->d_flux_arena.alloc((size_t)n * 5 * nl);
@@ -1226,19 +1390,50 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
   r->column_has_particles = r->np > 0;
   const int first_call = r->call_id + 1;
   std::vector<double> out((size_t)n * 5 * nl);
+  // One launch of each kernel per chunk of columns (the fused grid takes the columns' work items in
+  // turn, so one column's two-stream tail runs beside the next column's opacity tiles) where the fused
+  // form covers the configuration; otherwise the calls of the columns are enqueued back to back.
+  const int CH = std::min(n, r->batch_cols_in_flight);
+  const char *ts_mode = getenv("CLIMA_HIP_TS_MODE");
+  bool one_launch = r->fused && r->ng == 8 && !(ts_mode && std::strcmp(ts_mode, "block") == 0) && (nz + 63) / 64 >= 2 && (nz + 63) / 64 <= 8 &&
+                    (int)r->zenith_u.size() <= MAX_ZEN && !((nz + 63) / 64 > 4 && (r->rebin_mode != 0 || r->cust_on)) &&
+                    integrate_chunks(std::max(r->ir_n, r->sol_n)) * (32 + 16) * sizeof(double) <= 64 * 1024;
+  if (const char *e = getenv("CLIMA_HIP_BATCH_ONE_LAUNCH")) one_launch = one_launch && atoi(e) != 0;
+  const size_t tiles = ((size_t)r->op_n * nz + 255) / 256;
+  if (one_launch) {
+    const size_t pc = r->prep_count, oc = r->opr_count, rc = res_block_count(r);
+    if (r->d_prep_arena.n < pc * CH) r->d_prep_arena.alloc(pc * CH);
+    if (r->d_opr_arena.n < oc * CH) r->d_opr_arena.alloc(oc * CH);
+    if (r->d_res_arena.n < rc * CH) { r->d_res_arena.alloc(rc * CH); r->d_res_arena.zero(r->stream); }
+    if (r->d_done.n < tiles * CH + 1) { r->d_done.alloc(tiles * CH + 1); r->d_done.zero(r->stream); }
+  }
   auto run_all = [&](bool allow_fused) {
-    for (int c = 0; c < n; c++) {
-      r->col_override = r->d_cols_arena.p + (size_t)c * cc;
-      r->flux_override = r->d_flux_arena.p + (size_t)c * 5 * nl;
-      r->ftot_override = r->flux_override + 4 * nl;
-      try {
-        enqueue_radiate(r, true, true, allow_fused);
-      } catch (...) {
-        r->col_override = r->flux_override = r->ftot_override = nullptr;
-        throw;
+    if (one_launch && allow_fused) {
+      for (int c0 = 0; c0 < n; c0 += CH) {
+        BatchCtx bc;
+        bc.ncol = std::min(CH, n - c0);
+        bc.col = r->d_cols_arena.p + (size_t)c0 * cc;
+        bc.prep = r->d_prep_arena.p; bc.opr = r->d_opr_arena.p; bc.res = r->d_res_arena.p;
+        bc.flux = r->d_flux_arena.p + (size_t)c0 * 5 * nl;
+        bc.done = r->d_done.p;
+        bc.bs = BatchStrides{cc, r->prep_count, r->opr_count, res_block_count(r), (size_t)5 * nl, (int)tiles};
+        enqueue_radiate(r, true, true, true, &bc);
       }
+    } else {
+      for (int c = 0; c < n; c++) {
+        r->col_override = r->d_cols_arena.p + (size_t)c * cc;
+        r->nsrc_override = nsrc_h[c];
+        r->flux_override = r->d_flux_arena.p + (size_t)c * 5 * nl;
+        r->ftot_override = r->flux_override + 4 * nl;
+        try {
+          enqueue_radiate(r, true, true, allow_fused);
+        } catch (...) {
+          r->col_override = r->flux_override = r->ftot_override = nullptr;
+          throw;
+        }
+      }
+      r->col_override = r->flux_override = r->ftot_override = nullptr;
     }
-    r->col_override = r->flux_override = r->ftot_override = nullptr;
     HIPCHK(hipMemcpyAsync(out.data(), r->d_flux_arena.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, r->stream));
     HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, r->stream));
     // the handle's own level fluxes = the last column's
@@ -1254,6 +1449,7 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
   r->checked_timeout = r->call_id;
   r->small_valid = false;
   r->column_loaded = false;   // d_col does not hold the last column: a resident call needs an upload first
+  r->opr_valid = !one_launch;  // the one-launch form leaves the optical properties in the batch arena, not in the handle
   if (*r->h_errflag >= first_call) {
     r->checked_id = r->call_id;
     set_err(err, "Opacity computation failed in one or more wavelength bins.");  // clima_radtran_types.f90:773-776
@@ -1559,6 +1755,7 @@ void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, cons
   d_zw.upload(std::vector<double>{1.0});
   d_ziu.upload(std::vector<double>{1.0 / sol_par[0]});
   d_out.alloc((size_t)7 * nl); d_out.zero();
+  DevBuf<int> d_qm;
   TwoStreamParams ts;
   std::memset(&ts, 0, sizeof(ts));
   ts.nz = nz; ts.ng = ng;
@@ -1578,7 +1775,10 @@ void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, cons
   size_t lds = 0;
   if (*form == 0) ok = launch_twostream_w(ts, nullptr, &lds, false);
   else if (*form == 1) ok = launch_twostream(ts, nullptr, &lds);
-  else if (*form == 2) ok = launch_fused_twostream_only(ts, *slots, nullptr);
+  else if (*form == 2) {
+    d_qm.upload(std::vector<int>{nz});  // the column's source-layer count
+    ok = launch_fused_twostream_only(ts, *slots, d_qm.p, nullptr);
+  }
   else if (*form == 3) { ts.b_T = 0; ts.b_Ts = 0; ts.b_out = 0; ok = launch_twostream_ir_batch(ts, 1, nullptr); }
   HIPCHK(hipGetLastError());
   if (!ok) throw HipFail{"clima_test_two_stream: this form does not cover the requested shape"};

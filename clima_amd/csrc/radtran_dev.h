@@ -23,6 +23,14 @@
 
 namespace clima {
 
+// Crossing windows of the window-form rebin (kernels.hip rb_lo / rb_hi), indexed by the output edge
+// 1..7: element range that can contain the crossing of that edge.  The host checks a handle's weights
+// against them (rebin_windows_fit, radtran_api.hip).
+constexpr int RB_WIN_LO[8] = {0, 1, 5, 10, 18, 27, 39, 52};        // any order of the sums
+constexpr int RB_WIN_HI[8] = {0, 11, 24, 36, 45, 53, 58, 62};
+constexpr int RB_TIGHT_LO[8] = {0, 5, 12, 19, 27, 35, 45, 55};     // x and y ascending: prefixes are down-sets of the 8x8 grid
+constexpr int RB_TIGHT_HI[8] = {0, 8, 18, 28, 36, 44, 51, 58};
+
 constexpr int MAX_K = 8;      // k-distribution species
 constexpr int MAX_XS = 16;    // per Xsection kind
 constexpr int MAX_PART = 4;   // particle species
@@ -80,11 +88,28 @@ struct SlotDev {
   int flag_clamp;  // particles: out-of-range radius is an error (types.f90:973-976)
 };
 
+// Flags of an entry of the compact source-layer list (ColumnDev::meta)
+constexpr int SRC_PAIR = 1 << 30;    // layer j+1 reuses this layer (pair_reuse, types.f90:621-632)
+constexpr int SRC_EXACT = 1 << 29;   // ... and every input of layer j+1 is bitwise equal to layer j's
+constexpr int SRC_LAYER = 0xffff;
+
+// Element strides from one column of a batch to the next (0 everywhere for a single call).  Every
+// per-column array of a group lives in ONE block per column with the same internal layout, so a
+// group needs one stride: the column inputs, the prep results, the optical properties, the per-bin
+// spectra, the level fluxes, the hand-off flags.
+struct BatchStrides {
+  size_t col, prep, opr, res, flux;
+  int done;
+};
+
 struct ColumnDev {
   const double *T, *P, *dz, *dens, *pdens, *radii;  // dens [nsp][nz], pdens/radii [np][nz]
+  // pair_reuse decided on the host when the column is uploaded (one definition of is_close for the
+  // grid size and the kernels): meta[0] = nsrc, meta[1 + m] = source layer m | SRC_* flags
+  // (ascending), meta[1 + nz + j] = source layer of layer j (j, or j-1 for the second of a pair)
+  const int *meta;
   double *log10P, *cols, *foreign_col;
   double *absw;    // [nabs][nz] per-layer weights of the absorption entries
-  int *src;        // source layer for interpolation (j, or j-1 under pair_reuse)
   int *ix;         // [nslots][nz]
   double *q;       // [nslots][nz]
   int *err_flag;   // device error word: id of the last call that clamped a particle radius
@@ -100,6 +125,7 @@ struct CustomDev {
 struct OpacityParams {
   int nz, nw, ng, nsp, np;
   int bin_lo, nbins;  // opacity bins handled by this launch
+  int nsrc;           // source layers of the column (host count, == meta[0]); nz for a batch (upper bound)
   int nk, nray, npart;
   KDev k[MAX_K];
   XsDev ray[MAX_XS];
@@ -111,17 +137,20 @@ struct OpacityParams {
   ColumnDev col;
   double *tau, *w0, *g, *tau_band;        // opr
   long long *stamps;                      // diagnostic build only (-DCLIMA_STAMPS); null otherwise
-  int multi_edge;                         // max(wxy) > min(wbin): a sorted element may span several output edges
+  int rebin_mode;                         // 0 window form (the weights fit the compiled crossing windows), 1 streaming,
+                                          // 2 streaming with max(wxy) > min(wbin): an element may span several output edges
   CustomDev cust;
 };
 
 struct PrepParams {
-  int nz, nsp, np, nslots, has_cont, LH2O, check_radii;
+  int ncol;                  // gridDim.y: columns of a batch (1 for a single call)
+  BatchStrides bs;
+  int nz, nsp, np, nslots, has_cont, LH2O;
   int call_id;  // stamped into err_flag by a failing call (monotonic, so the flag never needs a reset)
   SlotDev slots[MAX_SLOTS];
   int nabs;
   int abs_kind[MAX_ABS], abs_a[MAX_ABS], abs_b[MAX_ABS];
-  int nzero;                 // output arrays cleared by spare blocks of the prep launch
+  int nzero;                 // output arrays cleared by spare blocks of the prep launch (per column: + c*bs.res)
   double *zero_ptr[6];
   size_t zero_count[6];
   ColumnDev col;
@@ -164,18 +193,25 @@ struct TwoStreamParams {
   double *sol_fup_a, *sol_fdn_a, *sol_amean, *sol_tau_band;
 };
 
-// fused opacity + two-stream launch (k_fused)
+// fused opacity + two-stream launch (k_fused), one workgroup per item.  Items of column c are the
+// blocks [c*(n_op+n_ts), (c+1)*(n_op+n_ts)): first its n_op opacity tiles, then its n_ts two-stream
+// items (one per (bin, g-point group), ordered by readiness).
 struct FusedParams {
-  int n_op;        // opacity blocks at the front of the grid (launcher)
-  int call_id;     // value an opacity block publishes in done[block] when its results are out
-  int max_spins;   // bound of a two-stream block's wait
-  int *done;       // [n_op]
-  int *timeout_flag;  // id of the last call in which a two-stream block's wait expired
-  int slots;       // layers per lane of the two-stream part: ceil(nz/64) = 2..4 (launcher)
-  int sol_early;   // solar bins whose opacities the first round of opacity blocks produces (launcher)
+  int ncol;        // columns in this launch
+  int n_op;        // opacity tiles per column (launcher; an upper bound when layers are reused)
+  int n_ts;        // two-stream items per column (launcher)
+  int call_id;     // value an opacity tile publishes in done[c][tile] when its results are out
+  int max_spins;   // bound of a two-stream item's wait
+  int *done;       // [ncol][n_op]
+  int *timeout_flag;  // id of the last call in which a two-stream item's wait expired
+  int slots;       // layers per lane of the two-stream part: ceil(nz/64) (launcher)
+  int sol_early;   // solar bins whose opacities the first round of opacity tiles produces (launcher)
+  BatchStrides bs;
 };
 
 struct IntegrateParams {
+  int ncol;                                // gridDim.z
+  BatchStrides bs;
   int nz;
   int nw_ir, nw_sol;
   int ir_lo, ir_n, sol_lo, sol_n;          // bins owned by this rank (all when unsharded)
@@ -208,9 +244,11 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
 // T + c*b_T, T_surface + c*b_Ts, IR spectra + c*b_out for column c of ncol
 bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s);
 bool fused_supported(const OpacityParams &op, const TwoStreamParams &ts);
+int fused_tiles(const OpacityParams &op);   // opacity tiles per column (size of a column's done[] slice)
 bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s);
 // test hook: the two-stream blocks of the fused grid alone (no opacity blocks), on opacities already in HBM
-bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, hipStream_t s);
+// (meta_nsrc: a device int, any value >= 1)
+bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s);
 int twostream_w_groups(int ng);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
 void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t s);
