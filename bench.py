@@ -2,25 +2,42 @@
 """Benchmark of the radiate() hot path (BASELINE.json: `radiate() calls/sec`, 200-layer
 ModernEarth column, full solar+IR correlated-k bin grid).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
 A "step" is ONE full `Radtran%radiate` call -- opacity assembly + IR + solar two-stream +
 spectral integration -- on the ModernEarth column of tests/test_radtran.f90 (config 2:
 nz=200, nw=1000 opacity bins (600 IR / 600 solar), 8 g-points, 8 zenith angles, 5
 k-distribution species, synthetic tables: SURVEY.md 8(d)).  Inputs (tables and the
-column) are resident in HBM before the timed region starts; the PCIe-inclusive rate is
-reported separately in DESIGN.md.
+column) are resident in HBM before the timed region starts.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the spectral bins of the SAME
-call are sharded over the ranks (work-balanced contiguous ranges) and every step ends with
-one RCCL all-reduce of the 4*(nz+1) partial level fluxes -- strong scaling of one call.
+What the one JSON line carries (rank 0):
+  value          resident form: K calls enqueued back to back on the handle's stream, bracketed by
+                 barrier + synchronise; the MEDIAN of `--repeats` such K-step timings (a 20-step run
+                 is 2.5 ms: one timing is a sample of the clock ramp), all of them listed in
+                 `repeats_calls_per_s`.
+  sync_api       the drop-in call of SURVEY.md 8(d) "Metric": `radtran_toa_fluxes_wrapper` with host
+                 arrays in, ISR / OLR out, one stream synchronise per call (PCIe inclusive); median,
+                 p10, p90 over >= 30 calls.  This is what a Fortran / Python caller of `TOA_fluxes`
+                 sees, and what `cpu_baseline` is comparable with.
+  roofline       dominant kernel, HIP events on the library's stream inside the timed region;
+                 `fp64_issue_frac` = VALU instructions per launch (PMC pass under profiles/) x 4
+                 cycles / (1024 SIMDs x 2.4 GHz) / kernel time; `traffic` from the PMC pass.  Both PMC
+                 figures are printed only when clima_amd/csrc/kernels.hip still has the hash recorded
+                 beside the PMC summary (profiles/r02_pmc.json) -- otherwise null.
+  algorithmic    N_PT, N_T and both byte variants of SURVEY.md 8(d).
+  cpu_baseline   the oracle on this box's host cores, same workload (a reported baseline).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP
-events on the stream it is launched on; `cpu_baseline` is the oracle (a port of the
-reference's algorithm, OpenMP over bins exactly like the reference) timed on this box's
-host cores on the same workload.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the spectral bins of the SAME call are
+sharded over the ranks (work-balanced contiguous ranges) and every step ends with one RCCL
+all-reduce of the 4*(nz+1) partial level fluxes -- strong scaling of one call.
+
+--config 3 (EarlyMars, CIA-heavy, 200 layers), 4 (1024 perturbed columns through
+radtran_toa_fluxes_batch: columns/s; with N > 1 every rank takes 1024/N columns, no collective) and
+5 (one 500-layer column; with N > 1 bins sharded + all-reduce) print the same kind of line for the
+other BASELINE.json configurations; the driver's default run is config 2.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,13 +47,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS, CLOCK_GHZ, F64_CYCLES = 1024, 2.4, 4.0   # 256 CUs x 4 SIMDs; one wave64 f64 instruction per SIMD per 4 cycles
 KERNELS = ["prep", "opacity", "twostream", "integrate"]
 EVENT_STRIDE = 16  # HIP events around the dominant kernel on every 16th launch of the timed region (first one included)
-# HBM bytes of one k_opacity8 launch on this exact workload from the PMC passes committed under
-# profiles/ (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; bench.py cannot collect counters itself)
-PMC_TRAFFIC_BYTES = {"fused": (2.732e4 + 4.737e4) * 1024.0,      # profiles/r01j_pmc_summary.md, k_fused
-                     "opacity": (1.640e4 + 4.681e4) * 1024.0}    # profiles/r01d_pmc_summary.md, k_opacity8
-PMC_TRAFFIC_SOURCE = "FETCH_SIZE + WRITE_SIZE (KiB) of the dominant kernel per launch: profiles/r01j_pmc_summary.md (k_fused), profiles/r01d_pmc_summary.md (k_opacity8)"
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+KERNEL_SRC = os.path.join(ROOT, "clima_amd", "csrc", "kernels.hip")
+
+
+def pmc_for(kernel, workload_key):
+    """PMC figures of `kernel` on `workload_key` from the committed pass -- only if the kernels are
+    still the ones that were profiled."""
+    try:
+        with open(PMC_FILE) as f:
+            rec = json.load(f)
+        with open(KERNEL_SRC, "rb") as f:
+            h = hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None, "no PMC record (%s)" % os.path.relpath(PMC_FILE, ROOT)
+    if rec.get("kernels_hip_sha256") != h:
+        return None, "stale: kernels.hip changed since the PMC pass of %s" % rec.get("source")
+    k = rec.get("workloads", {}).get(workload_key, {}).get(kernel)
+    if not k:
+        return None, "no PMC pass for %s on %s" % (kernel, workload_key)
+    return k, rec.get("source")
 
 
 def main():
@@ -44,8 +77,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--nz", type=int, default=200)
-    ap.add_argument("--nzen", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--nz", type=int, default=None)
+    ap.add_argument("--nzen", type=int, default=None)
+    ap.add_argument("--ncol", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -80,10 +116,27 @@ def main():
     from clima_amd import synthetic as S
     from clima_amd.radtran import Radtran
 
-    nz, nzen = args.nz, args.nzen
-    tables = S.modern_earth_tables()
-    col = S.modern_earth_column(nz)
-    rad = Radtran(tables, nz, nzen, 0.15)  # tests/test_radtran.f90:35-38
+    cfg = args.config
+    if cfg == 3:      # EarlyMars, CIA-heavy, nzen 4, albedo 0.2, photon scale 0.4286
+        nz, nzen, albedo = args.nz or 200, args.nzen or 4, 0.2
+        tables, col = S.early_mars_tables(), S.early_mars_column(nz)
+        what = "EarlyMars column (CO2-dominated, CIA-heavy), one Radtran%%radiate call: nz=%d, nw=1000, 8 g-points, %d zenith angles; config 3 of BASELINE.json" % (nz, nzen)
+    elif cfg == 5:    # one 500-layer column
+        nz, nzen, albedo = args.nz or 500, args.nzen or 8, 0.15
+        tables, col = S.modern_earth_tables(), S.modern_earth_column(nz)
+        what = "ModernEarth column, one Radtran%%radiate call: nz=%d, nw=1000, 8 g-points, %d zenith angles; config 5 of BASELINE.json" % (nz, nzen)
+    else:
+        nz, nzen, albedo = args.nz or 200, args.nzen or 8, 0.15
+        tables, col = S.modern_earth_tables(), S.modern_earth_column(nz)
+        what = ("ModernEarth column, one Radtran%%radiate call: nz=%d, nw=1000 (600 IR + 600 solar bins), 8 g-points, "
+                "%d zenith angles, nk=5; config 2 of BASELINE.json" % (nz, nzen))
+    rad = Radtran(tables, nz, nzen, albedo)  # tests/test_radtran.f90:35-38
+    if cfg == 3:
+        rad.photon_scale_factor = 0.4286
+
+    if cfg == 4:
+        return config4(args, rad, tables, nz, nzen, world, rank, dist_on, dist, torch, json_fd)
+
     if dist_on:
         rad.set_bin_shard(rank, world)
         fake = os.environ.get("CLIMA_BENCH_FAKE_SHARD")   # "rank,world": rehearse one rank's share of an N-GPU step on one GPU
@@ -140,28 +193,48 @@ def main():
     rad.profile(2)
     rad.profile_stride(EVENT_STRIDE)
     rad.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(max(args.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        dts.append(dt)
+    dt = float(np.median(dts))
     kt_dom = rad.kernel_time(1)
     if kt_dom[1] > 0:
         kt[1] = kt_dom
     rad.profile_stride(1)
     rad.profile(False)
 
-    if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    # ---- the synchronous drop-in call (host arrays in, ISR / OLR out, one stream sync per call)
+    sync_api = None
+    if not dist_on:
+        a = col.args()
+        for _ in range(10):
+            rad.TOA_fluxes(*a)
+        ts = []
+        for _ in range(100):
+            t0 = time.perf_counter()
+            rad.TOA_fluxes(*a)
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts) * 1e6
+        sync_api = {"what": "radtran_toa_fluxes_wrapper: host arrays in, ISR/OLR out, one stream synchronise per call (PCIe inclusive), through the ctypes mirror",
+                    "calls_per_s": 1e6 / float(np.median(ts)), "us_median": float(np.median(ts)),
+                    "us_p10": float(np.percentile(ts, 10)), "us_p90": float(np.percentile(ts, 90)), "n": len(ts)}
+        rad.upload_column(*a)
 
     # ---- companion figure for N > 1 (not `value`): the column-parallel form of config 4 --
     # every rank runs whole, unsharded calls on its own column, no collective (weak scaling)
     col_par = None
     if dist_on:
-        rad2 = Radtran(tables, nz, nzen, 0.15)
+        rad2 = Radtran(tables, nz, nzen, albedo)
         rad2.upload_column(*col.args())
         for _ in range(args.warmup):
             rad2.radiate_resident()
@@ -177,10 +250,12 @@ def main():
         del rad2
 
     # ---- parity of what was just timed (rank 0 checks OLR against the oracle)
-    isr = float((flux[3 * (nz + 1) + nz] - flux[2 * (nz + 1) + nz]).item()) if dist_on else None
     if dist_on:
+        isr = float((flux[3 * (nz + 1) + nz] - flux[2 * (nz + 1) + nz]).item())
         olr = -float((flux[1 * (nz + 1) + nz] - flux[0 * (nz + 1) + nz]).item())
     else:
+        rad.radiate_resident()
+        rad.synchronize()
         w_ir, w_sol = rad.wrk_ir, rad.wrk_sol
         olr = -(w_ir.fdn_n[nz] - w_ir.fup_n[nz])
         isr = w_sol.fdn_n[nz] - w_sol.fup_n[nz]
@@ -194,39 +269,98 @@ def main():
         per_kernel_us = {k: (1e3 * ms / n if n else 0.0) for k, (ms, n) in zip(names, kt) if n}
         dom = max(per_kernel_us, key=per_kernel_us.get)
         ab = rad.algorithmic_bytes()
+        nodes = rad.algorithmic_nodes()
         # algorithmic bytes of one call: distinct table nodes + inputs + outputs,
         # prorated to the bins this rank owns
         frac = rad.bin_shard()[1] / float(tables.nw)
         b_alg = (ab["tables_distinct"] + ab["output"]) * frac + ab["input"]
+        b_alg_full = (ab["tables_full"] + ab["output"]) * frac + ab["input"]
         dur = per_kernel_us[dom] * 1e-6
+        wkey = "config%d_nz%d_nzen%d" % (cfg, nz, nzen)
+        pmc, pmc_src = (None, "bins sharded: no PMC pass") if dist_on else pmc_for("k_" + dom, wkey)
+        issue = None
+        if pmc and dur > 0 and pmc.get("SQ_INSTS_VALU"):
+            issue = pmc["SQ_INSTS_VALU"] * F64_CYCLES / (SIMDS * CLOCK_GHZ * 1e9) / dur
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": b_alg / dur / 1e9 if dur > 0 else 0.0,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (b_alg / dur / 1e9) / HBM_PEAK_GBS if dur > 0 else 0.0,
-                    "traffic": PMC_TRAFFIC_BYTES.get(dom) if (not dist_on and (nz, nzen) == (200, 8)) else None,
-                    "traffic_source": PMC_TRAFFIC_SOURCE,
+                    "traffic": (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None,
+                    "traffic_source": "FETCH_SIZE + WRITE_SIZE (KiB) of the kernel per launch, %s" % pmc_src,
+                    "fp64_issue_frac": issue,
+                    "fp64_issue_source": ("SQ_INSTS_VALU = %.4g per launch (%s) x %g cycles / (%d SIMDs x %g GHz) / kernel time"
+                                          % (pmc["SQ_INSTS_VALU"], pmc_src, F64_CYCLES, SIMDS, CLOCK_GHZ)) if issue else pmc_src,
                     "algorithmic_bytes": b_alg, "kernel_us": per_kernel_us,
                     "whole_call_frac": (b_alg / (dt / args.steps) / 1e9) / HBM_PEAK_GBS}
         out = {"metric": "radiate() calls/sec", "value": value, "unit": "calls/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "ModernEarth column, one Radtran%%radiate call: nz=%d, nw=1000 "
-                                      "(600 IR + 600 solar bins), 8 g-points, %d zenith angles, nk=5; "
-                                      "config 2 of BASELINE.json" % (nz, nzen),
+               "config": {"workload": what,
                           "parallelism": ("bins sharded over %d GPUs + 1 all-reduce of %d f64" % (world, 4 * (nz + 1)))
                           if world > 1 else "1 GPU"},
-               "olr_W_m2": olr / 1e3, "isr_W_m2": isr / 1e3, "roofline": roofline}
+               "value_is": "median of %d repeats of the %d-step loop, resident inputs, calls enqueued back to back" % (len(dts), args.steps),
+               "repeats_calls_per_s": [args.steps / x for x in dts],
+               "olr_W_m2": olr / 1e3, "isr_W_m2": isr / 1e3, "roofline": roofline,
+               "algorithmic": {"N_PT": nodes["N_PT"], "N_PT_table": nodes["N_PT_full"], "N_T": nodes["N_T"],
+                               "N_T_table": nodes["N_T_full"], "bytes_distinct_nodes": b_alg,
+                               "bytes_whole_tables": b_alg_full,
+                               "frac_whole_tables": (b_alg_full / dur / 1e9) / HBM_PEAK_GBS if dur > 0 else 0.0}}
+        if sync_api is not None:
+            out["sync_api"] = sync_api
         if col_par is not None:
             out["column_parallel"] = col_par
         if not args.no_cpu_baseline and world == 1:
-            out.update(cpu_baseline(tables, col, nz, nzen, olr, rad))
+            out.update(cpu_baseline(tables, col, nz, nzen, albedo, olr, rad, 0.4286 if cfg == 3 else None))
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist_on:
         dist.destroy_process_group()
 
 
-def cpu_baseline(tables, col, nz, nzen, olr_gpu, rad=None):
+def config4(args, rad, tables, nz, nzen, world, rank, dist_on, dist, torch, json_fd):
+    """BASELINE.json config 4: `--ncol` perturbed ModernEarth columns (seed 7) through
+    radtran_toa_fluxes_batch; a step = the whole batch; with N ranks every rank takes ncol/N columns,
+    no collective (weak scaling in columns per rank is not what is asked: the batch is fixed -> strong)."""
+    import numpy as np
+    from clima_amd import synthetic as S
+    cols = S.perturbed_columns(args.ncol, nz=nz, seed=7)
+    mine = cols[rank::world] if world > 1 else cols
+    steps, warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+    for _ in range(warm):
+        isr, olr = rad.TOA_fluxes_batch(mine)
+    dts = []
+    for _ in range(steps):
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        isr, olr = rad.TOA_fluxes_batch(mine)
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        dts.append(dt)
+    dt = float(np.median(dts))
+    if rank == 0:
+        out = {"metric": "columns/sec (radtran_toa_fluxes_batch)", "value": args.ncol / dt, "unit": "columns/s",
+               "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * dt, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "%d perturbed ModernEarth columns (T-P and mixing-ratio sweep, seed 7), nz=%d, nw=1000, 8 g-points, "
+                                      "%d zenith angles, host arrays in / ISR, OLR out per batch; config 4 of BASELINE.json" % (args.ncol, nz, nzen),
+                          "parallelism": "%d GPU(s), columns split, no collective" % world},
+               "us_per_column": 1e6 * dt / args.ncol * world, "value_is": "median of %d batches" % steps,
+               "olr_W_m2_mean": float(np.mean(olr)) / 1e3, "fused_fallbacks": rad.fused_fallbacks}
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist_on:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tables, col, nz, nzen, albedo, olr_gpu, rad=None, photon_scale=None):
     """The oracle (port of the reference algorithm, OpenMP over bins like the reference's
     `!$omp parallel do`) on this box's host cores: whole radiate() calls of the same
     workload, bounded to ~10-30 s in all.  Timed at all usable cores (the figure in `value`)
@@ -234,7 +368,9 @@ def cpu_baseline(tables, col, nz, nzen, olr_gpu, rad=None):
     from oracle import oracle as O
     O.build()
     cores = min(os.cpu_count() or 1, 16)
-    o = O.OracleRadtran(tables, nz, nzen, 0.15)
+    o = O.OracleRadtran(tables, nz, nzen, albedo)
+    if photon_scale is not None:
+        o.set_scalars(photon_scale_factor=photon_scale)
 
     def timed(threads, budget, cap):
         O.lib().orc_set_num_threads(threads)

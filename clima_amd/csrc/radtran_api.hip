@@ -1661,6 +1661,45 @@ void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double 
   *bytes_out = 8.0 * ((2.0 * (nz + 1) + nz) * r->ir.nw + (3.0 * (nz + 1) + nz) * r->sol.nw + 5.0 * (nz + 1));
 }
 
+// N_PT = distinct (P,T) nodes of a k-table that the last uploaded column's bilinear
+// stencils touch (mean over the k-tables; <= nP*nT), N_T likewise for the 1-D (temperature) tables.
+void radtran_algorithmic_nodes(void *ptr, double *n_pt, double *n_pt_full, double *n_t, double *n_t_full, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2 || !r->column_loaded) { set_err(err, "no column has been uploaded"); return; }
+  const int nz = r->nz;
+  std::vector<double> lp(nz);
+  for (int j = 0; j < nz; j++) lp[j] = std::log10(r->last_P[j]);
+  double spt = 0.0, sptf = 0.0;
+  for (auto *k : r->k) {
+    std::set<std::pair<int, int>> s;
+    const double plo = *std::min_element(k->log10P.begin(), k->log10P.end()), phi = *std::max_element(k->log10P.begin(), k->log10P.end());
+    const double tlo = *std::min_element(k->temp.begin(), k->temp.end()), thi = *std::max_element(k->temp.begin(), k->temp.end());
+    for (int j = 0; j < nz; j++) {
+      const int iP = host_bracket(k->log10P, std::min(std::max(lp[j], plo), phi));
+      const int iT = host_bracket(k->temp, std::min(std::max(r->last_T[j], tlo), thi));
+      for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) s.insert({iP + a, iT + b});
+    }
+    spt += (double)s.size(); sptf += (double)k->nP * k->nT;
+  }
+  auto nodes1d = [&](const std::vector<double> &axis) {
+    std::set<int> s;
+    const double lo = *std::min_element(axis.begin(), axis.end()), hi = *std::max_element(axis.begin(), axis.end());
+    for (double v : r->last_T) { const int i = host_bracket(axis, std::min(std::max(v, lo), hi)); s.insert(i); s.insert(i + 1); }
+    return (double)s.size();
+  };
+  double st = 0.0, stf = 0.0;
+  int n1 = 0;
+  for (auto *v : {&r->cia, &r->pxs})
+    for (auto *xs : *v)
+      if (xs->dim) { st += nodes1d(xs->temp); stf += xs->nT; n1++; }
+  if (r->has_cont) { st += 2 * nodes1d(r->cont_temp); stf += 2 * r->cont_nT; n1 += 2; }
+  *n_pt = r->k.empty() ? 0.0 : spt / r->k.size();
+  *n_pt_full = r->k.empty() ? 0.0 : sptf / r->k.size();
+  *n_t = n1 ? st / n1 : 0.0;
+  *n_t_full = n1 ? stf / n1 : 0.0;
+}
+
 #ifdef CLIMA_STAMPS
 extern "C" void clima_debug_stamps(void *ptr, long long *out) {
   Radtran *r = as_rad(ptr);

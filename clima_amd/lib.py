@@ -58,6 +58,7 @@ SIGNATURES = {
     "radtran_profile_reset": [_vp],
     "radtran_profile_stride_set": [_vp, _ip],
     "radtran_algorithmic_bytes": [_vp, _dp, _dp, _dp, _dp, _err],
+    "radtran_algorithmic_nodes": [_vp, _dp, _dp, _dp, _dp, _err],
     "radtran_opr_get": [_vp, _dp, _dp, _dp, _dp, _err],
     "clima_test_device_exp": [_ip, _dp, _dp, _err],
     "clima_test_device_rcp": [_ip, _dp, _dp, _err],

@@ -390,6 +390,13 @@ class Radtran:
         self._check()
         return dict(tables_distinct=a.value, input=b.value, output=c.value, tables_full=d.value)
 
+    def algorithmic_nodes(self):
+        """distinct interpolation nodes the uploaded column touches (N_PT, N_T) and the table sizes."""
+        v = [C.c_double() for _ in range(4)]
+        self._L.radtran_algorithmic_nodes(self._ptr, *[C.byref(x) for x in v], self._err)
+        self._check()
+        return dict(N_PT=v[0].value, N_PT_full=v[1].value, N_T=v[2].value, N_T_full=v[3].value)
+
     def opr(self):
         """OpticalPropertiesResult: tau,w0 (nz,ngauss,nw), g,tau_band (nz,nw); TOA-first."""
         nz, ng, nw = self.nz, self.ngauss, self.nw

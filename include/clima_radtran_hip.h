@@ -196,6 +196,10 @@ void radtran_profile_reset(void *ptr);
 void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double *bytes_in,
                                double *bytes_out, double *bytes_tables_full, char *err);
 
+/* N_PT (distinct (P,T) k-table nodes the last uploaded column touches, mean over the
+ * k-tables, and the table's nP*nT) and N_T (the same for the 1-D temperature tables) */
+void radtran_algorithmic_nodes(void *ptr, double *n_pt, double *n_pt_full, double *n_t, double *n_t_full, char *err);
+
 /* test hook: y[i] = the kernels' device exp(x[i]) (used where the reference calls exp) */
 void clima_test_device_exp(const int *n, const double *x, double *y, char *err);
 /* test hook: the device reciprocal with 0, 1 and 2 Newton steps, and the device sqrt of |x|
