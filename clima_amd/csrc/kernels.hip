@@ -185,6 +185,51 @@ __device__ __forceinline__ double fast_exp(double x, const ExpK &K) {
   return exp_scale(p, k);
 }
 
+// exp(x) for attenuation factors (x <= 0 in exact arithmetic; anything up to ~700 is fine): table form,
+//   x = n*ln2/64 + r,  exp(x) = 2^(n>>6) * 2^((n&63)/64) * exp(r),  |r| <= ln2/128,
+// with the 64 correctly rounded values 2^(i/64) in LDS and a degree-5 polynomial for exp(r) (truncation
+// 3e-17): 16 instructions + one LDS read where fast_exp() takes 23.  <= 1.5 ulp.  Used where a wave
+// evaluates many exponentials whose results are then summed with weights (the zenith-angle loop).
+__device__ const double EXP2_TAB[64] = {
+    1, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.1023825833078409, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.2021567314527031, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.2553807570246911, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.3396675240533029,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.5590044002378369, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.6457554781539649, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.7186192981224779, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.9784560263879509};
+__device__ __forceinline__ double exp_tab(double x, const double *s_tab) {
+  x = dmax(x, -800.0);  // exp underflows to 0 long before; keeps the reduction below in range
+  const double nf = __builtin_rint(x * 92.33248261689366);    // 64/ln2
+  double r = __builtin_fma(nf, -0.01083042469326756, x);      // ln2/64, leading 32 bits: nf*hi is exact
+  r = __builtin_fma(nf, -2.9815858269852933e-12, r);
+  const int n = (int)nf;
+  const double t = s_tab[n & 63];
+  double p = 8.3333333333333332e-03;
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(t * p, n >> 6);
+}
+// 1/x with one Newton step on v_rcp_f64: relative error <= 2e-15 (tests/devtools/gpu_rcp_accuracy.py),
+// for factors that enter sums of weighted source terms
+__device__ __forceinline__ double rcp_n1(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
 // ten2power, src/clima_eqns.f90:75-80
 __device__ __forceinline__ double ten2power(double y) { return fast_exp(y * LN10); }
 
@@ -1781,7 +1826,10 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 
   if constexpr (solar) {
     // ---- delta-Eddington (:38-40), quadrature coefficients (:43-44), lambda, Gamma (:50-51)
-    double taup[L], w0p[L], gtp[L], gam1[L], gam2[L], lam2[L];
+    // exp table of the zenith-angle loop (exp_tab)
+    __shared__ double s_e2[64];
+    if (threadIdx.x < 64) s_e2[threadIdx.x] = EXP2_TAB[threadIdx.x];
+    double taup[L], lam2[L], zA[L], zB[L], zH[L];
     double tot = 0.0;
 #pragma unroll
     for (int t = 0; t < L; t++) {
@@ -1790,25 +1838,33 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     }
     // optical depth above the chunk (tauc, :64-67): exclusive wave scan of the chunk totals
     double tcum = wave_shr1(wscan_sum(tot));  // DPP scans: no LDS round trips (0 enters lane 0)
-    double tauc[L];
+    double tauc0 = tcum;
 #pragma unroll
     for (int t = 0; t < L; t++) {
       // quotients with denominators of ordinary size: numerator times the correctly rounded
       // reciprocal (6 instructions instead of the 11 of a full division, <= 1 ulp)
-      w0p[t] = w0_s[t] * (1.0 - gt_s[t] * gt_s[t]) * rcp_nr(1.0 - w0_s[t] * gt_s[t] * gt_s[t]);
-      gtp[t] = gt_s[t] * rcp_nr(1.0 + gt_s[t]);
-      gam1[t] = sqrt3 * (2.0 - w0p[t] * (1 + gtp[t])) / 2.0;
-      gam2[t] = sqrt3 * w0p[t] * (1.0 - gtp[t]) / 2.0;
-      const double lam = sqrt_nr(gam1[t] * gam1[t] - gam2[t] * gam2[t]);
-      G[t] = gam2[t] * rcp_nr(gam1[t] + lam);
+      const double w0p = w0_s[t] * (1.0 - gt_s[t] * gt_s[t]) * rcp_nr(1.0 - w0_s[t] * gt_s[t] * gt_s[t]);
+      const double gtp = gt_s[t] * rcp_nr(1.0 + gt_s[t]);
+      const double gam1 = sqrt3 * (2.0 - w0p * (1 + gtp)) / 2.0;
+      const double gam2 = sqrt3 * w0p * (1.0 - gtp) / 2.0;
+      const double lam = sqrt_nr(gam1 * gam1 - gam2 * gam2);
+      G[t] = gam2 * rcp_nr(gam1 + lam);
       X[t] = fexp(-lam * taup[t]);  // :56
       // a zero-thickness slot has w0p = 0, so its C+/C- vanish whatever the denominator
       // lam^2 - 1/u0^2 is -- as long as that is not 0 (u0 = 1/sqrt(3)): keep it away from 0
       lam2[t] = (t >= pad) ? lam * lam : -1.0;
-      tauc[t] = tcum;
+      // The source factors of :45-46 and :75-77 are affine in u0 and 1/u0:
+      //   w0 ((gam1 - 1/u0) gam3 + gam4 gam2) = (w0/2) (A - s),  w0 ((gam1 + 1/u0) gam4 + gam2 gam3) = (w0/2) (A + s),
+      //   gam3 = (1 - sqrt3 g u0)/2, gam4 = 1 - gam3,  A = gam1 + gam2 + sqrt3 g,  s = 1/u0 - sqrt3 g (gam2 - gam1) u0:
+      // 6 operations per (layer, zenith angle) instead of 14
+      const double a = sqrt3 * gtp;
+      zA[t] = gam1 + gam2 + a;
+      zB[t] = a * (gam2 - gam1);
+      zH[t] = 0.5 * w0p;
       tcum = tcum + taup[t];
       cp0[t] = cm0[t] = cpb[t] = cmb[t] = dir[t] = diru[t] = 0.0;
     }
+    __syncthreads();  // s_e2
     TSTAMP(1);
     // ---- C+/C- and direct beam (:73-87) summed over the zenith angles with their weights (the
     //      matrix does not depend on u0: sum_z w_z*solve(E_z) == solve(sum_z w_z*E_z)).  exp(-tauc/u0)
@@ -1818,22 +1874,21 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       const double u0 = p.zen_u_v[z], wz = p.zen_w_v[z], iu = p.zen_iu_v[z];
       wsum = wsum + wz;
       dir0 = dir0 + wz * u0;
-      double et = fexp(-tauc[0] * iu);
+      const double iu2 = iu * iu, wzu = wz * u0;
+      double et = exp_tab(-tauc0 * iu, s_e2);
 #pragma unroll
       for (int t = 0; t < L; t++) {
-        const double gam3 = (1.0 - sqrt3 * gtp[t] * u0) / 2.0;
-        const double gam4 = 1.0 - gam3;
-        const double facp = w0p[t] * ((gam1[t] - iu) * gam3 + gam4 * gam2[t]);
-        const double facm = w0p[t] * ((gam1[t] + iu) * gam4 + gam2[t] * gam3);
-        const double etb = et * fexp(-taup[t] * iu);  // :79
-        const double rden = wz * rcp_nr(lam2[t] - iu * iu);  // w_z / denom (:80)
-        const double fp = facp * rden, fm = facm * rden;
+        const double etb = et * exp_tab(-taup[t] * iu, s_e2);  // :79
+        const double H = zH[t] * (wz * rcp_n1(lam2[t] - iu2));  // (w0/2) * w_z / denom (:80)
+        const double sH = __builtin_fma(-zB[t], u0, iu) * H;
+        const double XH = zA[t] * H;
+        const double fp = XH - sH, fm = XH + sH;
         cp0[t] = __builtin_fma(et, fp, cp0[t]);
         cpb[t] = __builtin_fma(etb, fp, cpb[t]);
         cm0[t] = __builtin_fma(et, fm, cm0[t]);
         cmb[t] = __builtin_fma(etb, fm, cmb[t]);
-        dir[t] = __builtin_fma(wz * u0, etb, dir[t]);   // direct(i+1) = u0*etb (:82)
-        diru[t] = __builtin_fma(wz, etb, diru[t]);      // direct(i+1)/u0
+        dir[t] = __builtin_fma(wzu, etb, dir[t]);   // direct(i+1) = u0*etb (:82)
+        diru[t] = __builtin_fma(wz, etb, diru[t]);  // direct(i+1)/u0
         et = etb;
       }
     };
@@ -2088,14 +2143,14 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   const int groups = (p.ng + TSW_COLS - 1) / TSW_COLS;
   const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)p.nz + 1);  // level values of the columns + the bin's Planck table
   if (lds_bytes) *lds_bytes = lds;
-  if (lds > 160 * 1024) return false;
+  if (lds > 64 * 1024) return false;
   const int grid = p.n_sol + p.n_ir;
   if (grid <= 0) return true;
   if (groups > 1 && !zeroed) ts_zero_outputs(p, s);
   using Kern = void (*)(TwoStreamParams);
   static const Kern kern[8] = {k_twostream_w<1>, k_twostream_w<2>, k_twostream_w<3>, k_twostream_w<4>,
                                k_twostream_w<5>, k_twostream_w<6>, k_twostream_w<7>, k_twostream_w<8>};
-  if (!ensure_max_lds((const void *)kern[lmax - 1])) return false;
+  if (lds > 48 * 1024 && !ensure_max_lds((const void *)kern[lmax - 1], 64 * 1024)) return false;  // (static LDS on top)
   // Up to two g-point groups go in one launch: two partial sums added into a zeroed output
   // are order-independent.  More groups (ng > 8) run as one launch per group on the same
   // stream, each adding a single addend, so results stay bitwise reproducible.
