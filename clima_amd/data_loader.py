@@ -34,7 +34,7 @@ from . import h5lite
 from .radtran import ClimaException
 
 C_LIGHT = 299792458.0           # src/clima_const.f90
-LOG10TINY = np.log10(np.finfo(np.float64).tiny)   # clima_const.f90: log10(tiny(1.0_dp))
+LOG10TINY = float(np.log10(np.sqrt(np.finfo(np.float64).tiny)))   # src/clima_const.f90:21: log10(sqrt(tiny(1.0_dp)))
 HUGE = np.finfo(np.float64).max
 RDELTA = 1.0e-4
 

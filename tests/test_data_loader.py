@@ -124,6 +124,73 @@ def test_load_tables_round_trip(datadir):
     np.testing.assert_allclose(t.photons_sol, _bin_average(t.sol_wavl, xx, yy) * (wav * 1e-9 * wav / D.C_LIGHT), rtol=1e-10)
 
 
+def test_c_written_directory_is_chunked_deflated_and_partly_float32():
+    """tests/golden/datadir_c/ was written by tests/golden/h5pack.c (HDF5 C library: chunked layout,
+    shuffle + deflate, float32 storage for one k-table and the Mie tables), not by h5lite.write."""
+    import ctypes as C
+    from clima_amd import h5lite
+    from expected_tables import DATADIR_C
+    h = h5lite.lib()
+    hid = C.c_int64
+    for fn, res, args in (("H5Fopen", hid, [C.c_char_p, C.c_uint, hid]), ("H5Dopen2", hid, [hid, C.c_char_p, hid]),
+                          ("H5Dget_create_plist", hid, [hid]), ("H5Pget_layout", C.c_int, [hid]),
+                          ("H5Pget_nfilters", C.c_int, [hid]), ("H5Dget_type", hid, [hid]), ("H5Tget_size", C.c_size_t, [hid]),
+                          ("H5Pclose", C.c_int, [hid]), ("H5Tclose", C.c_int, [hid]), ("H5Dclose", C.c_int, [hid]),
+                          ("H5Fclose", C.c_int, [hid])):
+        getattr(h, fn).restype, getattr(h, fn).argtypes = res, args
+
+    def props(rel, name):
+        f = h.H5Fopen(os.path.join(DATADIR_C, rel).encode(), 0, 0)
+        assert f >= 0
+        d = h.H5Dopen2(f, name.encode(), 0)
+        pl, ty = h.H5Dget_create_plist(d), h.H5Dget_type(d)
+        out = (h.H5Pget_layout(pl), h.H5Pget_nfilters(pl), h.H5Tget_size(ty))
+        h.H5Pclose(pl); h.H5Tclose(ty); h.H5Dclose(d); h.H5Fclose(f)
+        return out
+
+    H5D_CHUNKED = 2
+    assert props("kdistributions/H2O.h5", "log10k") == (H5D_CHUNKED, 2, 8)
+    assert props("kdistributions/CO2.h5", "log10k") == (H5D_CHUNKED, 2, 4)        # float32 on disk
+    assert props("aerosol_xsections/khare1984/mie_khare1984.h5", "qext") == (H5D_CHUNKED, 2, 4)
+    assert props("CIA/N2-N2.h5", "log10xs")[:2] == (H5D_CHUNKED, 2)
+
+
+def test_c_written_directory_against_tables_built_without_the_loader():
+    """Every table the loader produces from tests/golden/datadir_c/ against tests/expected_tables.py,
+    which builds the same tables from the arrays that went into the files with its own regridding
+    routine (no clima_amd.data_loader, no h5lite)."""
+    from clima_amd import data_loader as D
+    from expected_tables import DATADIR_C, expected_tables
+    e = expected_tables()
+    t = D.load_tables(os.path.join(DATADIR_C, "settings.yaml"), os.path.join(DATADIR_C, "star.txt"), DATADIR_C)
+    assert t.species_names == e.species_names and t.particle_names == e.particle_names
+    np.testing.assert_allclose(t.wavl, e.wavl, rtol=1e-15)
+    np.testing.assert_allclose(t.ir_wavl, e.ir_wavl, rtol=1e-15)
+    np.testing.assert_allclose(t.sol_wavl, e.sol_wavl, rtol=1e-15)
+    assert len(t.ktables) == len(e.ktables) == 5
+    for a, b in zip(t.ktables, e.ktables):
+        assert a["sp_ind"] == b["sp_ind"]
+        for key in ("weights", "log10P", "temp", "log10k"):      # pass-through (float32 data widened exactly)
+            np.testing.assert_array_equal(a[key], b[key])
+    assert [(x["xs_type"], x["sp1"], x.get("sp2", -1)) for x in t.xsections] == \
+           [(x["xs_type"], x["sp1"], x.get("sp2", -1)) for x in e.xsections]
+    for a, b in zip(t.xsections, e.xsections):
+        np.testing.assert_allclose(a["data"], b["data"], rtol=1e-11)
+        if b["temp"] is not None:
+            np.testing.assert_array_equal(a["temp"], b["temp"])
+    for key in ("log10_H2O", "log10_foreign", "temp"):
+        np.testing.assert_allclose(t.continuum[key], e.continuum[key], rtol=1e-11)
+    assert t.continuum["LH2O"] == e.continuum["LH2O"]
+    for key in ("radii", "w0", "qext", "gt"):
+        np.testing.assert_allclose(t.particles[0][key], e.particles[0][key], rtol=1e-11)
+    np.testing.assert_allclose(t.photons_sol, e.photons_sol, rtol=1e-11)
+    # the padding value of the regridding is the reference's log10(sqrt(tiny)) (src/clima_const.f90:21):
+    # the first bin is only partly covered by the CIA data, so its average shows the pad
+    assert D.LOG10TINY == pytest.approx(-153.8263277842944, rel=1e-15)
+    cia = [x for x in t.xsections if x["xs_type"] == D.XS_CIA][0]["data"]
+    assert -130.0 < cia[0, 0] < -60.0
+
+
 def test_loaded_tables_drive_the_oracle(datadir, O):
     # what the loader returns is a complete table set: the CPU oracle runs on it
     from clima_amd import data_loader as D

@@ -497,6 +497,21 @@ def test_constructed_from_a_data_directory(O, tmp_path):
     _compare(r, o, S.modern_earth_column(40))
 
 
+def test_constructed_from_the_c_written_data_directory(O):
+    # tests/golden/datadir_c/: HDF5 files written by the HDF5 C library (chunked, deflate, float32 for
+    # one k-table and the Mie tables; tests/golden/h5pack.c), NOT by clima_amd/h5lite.py.  The HIP path is
+    # fed through the loader; the oracle gets tables built from the arrays that went into the files by
+    # tests/expected_tables.py, without the loader.
+    import os
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    from expected_tables import DATADIR_C, expected_tables
+    r = Radtran.from_files(os.path.join(DATADIR_C, "settings.yaml"), os.path.join(DATADIR_C, "star.txt"), 3, 0.2, 40, DATADIR_C)
+    o = O.OracleRadtran(expected_tables(), 40, 3, 0.2)
+    assert r.species_names == list(S.MODERN_EARTH_SPECIES) and r.particle_names == ["HCaer1"]
+    _compare(r, o, S.modern_earth_column(40))
+
+
 def test_column_batch_equals_one_call_per_column(O, small_tables):
     # BASELINE config 4 mechanics: radtran_toa_fluxes_batch enqueues the same kernels per column
     # without host round trips, so every column equals its own TOA_fluxes call bit for bit
