@@ -1055,8 +1055,296 @@ __global__ __launch_bounds__(64) void k_opacity_generic(OpacityParams p, int N2)
   }
 }
 
+// ------------------------------------------------------------------------------------
+// k_opacity_coop<NG>: NG lanes per (bin, source layer), NG = 8, 16 or 32 g-points.  Lane g of a
+// group owns g-point g: it interpolates that g-point's k-coefficient, and in a mixing step it holds
+// row g of the NG x NG sums (x_g + y_r, r = 0..NG-1) in registers.  The NG*NG keys are sorted ACROSS
+// the group by a bitonic network in its direction-free form (the first step of every merge level
+// mirrors the partner index, so all runs ascend): position = lane*NG + register; partners at a
+// distance below NG are registers of the same lane (one v_min + one v_max), partners further away sit
+// in the same (or the mirrored) register of lane^m and come over ds_swizzle.  Rows that already
+// ascend (k-coefficients ascending in g: the normal case) skip the levels that sort within a lane.
+// Rebin (weights_to_bins + futils rebin, types.f90:846-847) on the distributed sorted sequence: a
+// lane's keys are a contiguous run of ranks, so the running weight C and integral IC at its first key
+// come from an exclusive scan of the lanes' totals; output edge E_k is crossed inside exactly one
+// lane's run ((C_first, C_next_lane]), which evaluates I(E_k) = max_r [IC_r + v_r (E_k - C_r)] over its
+// keys (the window form of rorr_mix8) and hands it to lanes k-1 and k through LDS.
+// Two uses: (1) g-point counts 16 and 32 (NG^2 = 256 / 1024 keys do not fit one lane's registers);
+// (2) NG = 8 when a call has few (bin, layer) items -- a bin-sharded rank, a short column: the
+// lane-per-item kernel's 4 mixing steps are a ~30 us dependent chain however few items there are, this
+// form's chain is a fifth of that at 2.4x the total work.
+// Keys carry their pair index in the 2*log2(NG) low mantissa bits (ties ordered as the stable rank).
+// ------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ double swz_xor(double v) {  // v of lane (lane ^ M), M < 32
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_swizzle((int)b, (M << 10) | 0x1f);
+  const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), (M << 10) | 0x1f);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int NG>
+struct CoopSort {
+  // one step with partner position pos ^ X restricted to partners in another lane: lane ^ LM, register
+  // r ^ RM (RM = NG-1 mirrors the register index, 0 keeps it); `lower`: this lane holds the lower position
+  template <int LM, int RM>
+  static __device__ __forceinline__ void cross(double (&key)[NG], const bool lower) {
+    double b[NG];
+#pragma unroll
+    for (int r = 0; r < NG; r++) b[r] = swz_xor<LM>(key[r ^ RM]);
+#pragma unroll
+    for (int r = 0; r < NG; r++) key[r] = ((b[r] < key[r]) == lower) ? b[r] : key[r];
+  }
+  template <int X>
+  static __device__ __forceinline__ void intra(double (&key)[NG]) {  // partner register r ^ X, X < NG
+#pragma unroll
+    for (int r = 0; r < NG; r++) {
+      if ((r ^ X) > r) {
+        const double lo = dmin(key[r], key[r ^ X]), hi = dmax(key[r], key[r ^ X]);
+        key[r] = lo;
+        key[r ^ X] = hi;
+      }
+    }
+  }
+  // half-cleaner steps of level K: distances K/4, K/8, ..., 1
+  template <int K, int D>
+  static __device__ __forceinline__ void halves(double (&key)[NG], const int g) {
+    if constexpr (D >= 1) {
+      if constexpr (D >= NG) cross<D / NG, 0>(key, (g & (D / NG)) == 0);
+      else intra<D>(key);
+      halves<K, D / 2>(key, g);
+    }
+  }
+  template <int K>
+  static __device__ __forceinline__ void level(double (&key)[NG], const int g) {
+    // flip step: partner = pos ^ (K-1)
+    if constexpr (K <= NG) intra<K - 1>(key);
+    else cross<K / NG - 1, NG - 1>(key, (g & (K / (2 * NG))) == 0);
+    halves<K, K / 4>(key, g);
+  }
+  template <int K, int KMAX>
+  static __device__ __forceinline__ void levels(double (&key)[NG], const int g) {
+    if constexpr (K <= KMAX) {
+      level<K>(key, g);
+      levels<2 * K, KMAX>(key, g);
+    }
+  }
+};
+
+template <int NG, bool CUSTOM>
+__global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
+  constexpr int N2 = NG * NG, GROUPS = OP_THREADS / NG;
+  constexpr unsigned long long IDX_MASK = (unsigned long long)(N2 - 1);
+  __shared__ double s_wxy[N2];
+  __shared__ double s_E[NG + 1];
+  __shared__ double sIe[GROUPS][NG + 1];
+  const int tid = threadIdx.x;
+  for (int m = tid; m < N2; m += OP_THREADS) s_wxy[m] = p.wxy[m];
+  if (tid <= NG) s_E[tid] = p.wbin_e[tid];
+  __syncthreads();
+  const ColumnDev &c = p.col;
+  const int nz = p.nz;
+  const int g = tid & (NG - 1), grp = tid / NG;
+  const int nsrc = c.meta[0];
+  const long total = (long)p.nbins * nsrc;
+  long t = ((long)blockIdx.x * OP_THREADS + tid) / NG;
+  const bool valid = t < total;
+  if (!valid) t = total - 1;
+  const int l = p.bin_lo + (int)(t / nsrc);
+  const int ent = c.meta[1 + (int)(t % nsrc)];
+  const int j = ent & SRC_LAYER;
+  const bool pair = (ent & SRC_PAIR) != 0, exact = (ent & SRC_EXACT) != 0;
+  const int n = nz - 1 - j;
+  const double wg = p.wbin[g];
+  const double rWg = 1.0 / (s_E[g + 1] - s_E[g]);
+
+  // ---- layer terms (types.f90:665-757): every lane of the group evaluates them (a tenth of the work)
+  auto layer_terms = [&](const int jl, LayerTerms &o) {
+    const double dzj = c.dz[jl];
+    double tausg = 0.0;
+    for (int i = 0; i < p.nray; i++) tausg = tausg + p.ray[i].data[l] * c.cols[p.ray[i].sp1 * nz + jl];
+    double taua = 0.0;
+    for (int e = 0; e < p.nabs; e++) {
+      const AbsEntry &x = p.abs[e];
+      double sgm;
+      if (x.nT) {
+        const int ix = c.ix[x.slot * nz + jl];
+        const double q = c.q[x.slot * nz + jl];
+        const double *base = x.data + (size_t)l * x.nT + ix;
+        sgm = ten2power((1.0 - q) * base[0] + q * base[1]);
+      } else {
+        sgm = x.data[l];
+      }
+      taua = taua + sgm * c.absw[e * nz + jl];
+    }
+    double tauc = TINY, tausc = TINY * TINY, g0c = TINY;
+    if constexpr (CUSTOM) {
+      const int ix = c.ix[p.cust.slot * nz + jl];
+      const double q = c.q[p.cust.slot * nz + jl];
+      const size_t o2 = (size_t)l * p.cust.nP;
+      tauc = lerp1(p.cust.dtau + o2, ix, q) * dzj;
+      const double w0c = lerp1(p.cust.w0 + o2, ix, q);
+      g0c = lerp1(p.cust.g0 + o2, ix, q);
+      tausc = w0c * tauc;
+    }
+    double tausp = 0.0, taup = 0.0;
+    double tausp_1[MAX_PART], gtp[MAX_PART];
+    for (int i = 0; i < p.npart; i++) {
+      const PartDev &pt = p.part[i];
+      const int ix = c.ix[pt.slot * nz + jl];
+      const double q = c.q[pt.slot * nz + jl];
+      const double w0p = lerp1(pt.w0 + (size_t)l * pt.nrad, ix, q);
+      const double qext = lerp1(pt.qext + (size_t)l * pt.nrad, ix, q);
+      gtp[i] = lerp1(pt.gt + (size_t)l * pt.nrad, ix, q);
+      const double rr = c.radii[pt.p_ind * nz + jl];
+      const double taup_1 = qext * PI * (rr * rr) * c.pdens[pt.p_ind * nz + jl] * dzj;
+      taup = taup + taup_1;
+      tausp_1[i] = w0p * taup_1;
+      tausp = tausp + tausp_1[i];
+    }
+    double gt = 0.0;
+    for (int i = 0; i < p.npart; i++) gt = gt + gtp[i] * tausp_1[i] / fmax(TAU_MIN, (tausp + tausg + tausc));
+    gt = gt + g0c * tausc / fmax(TAU_MIN, (tausp + tausg + tausc));
+    gt = fmin(gt, MAX_GT);
+    o.tausg = tausg; o.taua = taua; o.tauc = tauc; o.tausc = tausc; o.taup = taup; o.tausp = tausp; o.gt = gt;
+  };
+  // k-coefficient of species s at this lane's g-point times the column of layer jl (:649-662, :818 / :828)
+  auto k_times_col = [&](const int s, const int jl) {
+    const KDev &kd = p.k[s];
+    const int iP = c.ix[kd.slotP * nz + j], iT = c.ix[kd.slotT * nz + j];
+    const double q1 = c.q[kd.slotP * nz + j], q2 = c.q[kd.slotT * nz + j];
+    const double p1 = 1.0 - q1, p2 = 1.0 - q2;
+    const double *f11 = kd.log10k + (size_t)l * kd.nT * kd.nP * NG + ((size_t)iT * kd.nP + iP) * NG;
+    const double *f21 = f11 + NG, *f12 = f11 + (size_t)kd.nP * NG, *f22 = f12 + NG;
+    const double fx1 = p1 * f11[g] + q1 * f21[g];
+    const double fx2 = p1 * f12[g] + q1 * f22[g];
+    return ten2power(p2 * fx1 + q2 * fx2) * c.cols[kd.sp * nz + jl];
+  };
+  LayerTerms lt;
+  layer_terms(j, lt);
+
+  const int gbase = (tid & 63) & ~(NG - 1);  // first lane of the group within the wave
+  double tk = k_times_col(0, j);
+  for (int s = 1; s < p.nk; s++) {
+    const double kc = k_times_col(s, j);
+    // ---- the row of this lane: x_g + y_r (tau_xy(:, r+(g-1)*ng), types.f90:828), pair index in the low bits
+    double key[NG];
+#pragma unroll
+    for (int r = 0; r < NG; r++) {
+      const double v = tk + __shfl(kc, gbase + r);
+      unsigned long long b = (unsigned long long)__double_as_longlong(v);
+      b = (b & ~IDX_MASK) | (unsigned long long)(g * NG + r);
+      key[r] = __longlong_as_double((long long)b);
+    }
+    // rows ascend when y does; otherwise sort within the lanes first
+    const double kc_next = __shfl_down(kc, 1);
+    const bool ys = __all(g == NG - 1 || kc <= kc_next);
+    if (!ys) CoopSort<NG>::template levels<2, NG>(key, g);
+    CoopSort<NG>::template levels<2 * NG, N2>(key, g);
+    // ---- rebin: weights in sorted order, running weight / integral at this lane's first key
+    double w[NG];
+#pragma unroll
+    for (int r = 0; r < NG; r++) w[r] = s_wxy[(int)((unsigned long long)__double_as_longlong(key[r]) & IDX_MASK)];
+    double Cw = 0.0, ICw = 0.0;
+#pragma unroll
+    for (int r = 0; r < NG; r++) { ICw = __builtin_fma(key[r], w[r], ICw); Cw = Cw + w[r]; }
+    double Cs = Cw, ICs = ICw;  // inclusive scan over the lanes of the group
+#pragma unroll
+    for (int d = 1; d < NG; d <<= 1) {
+      const double a = __shfl_up(Cs, d), b2 = __shfl_up(ICs, d);
+      if (g >= d) { Cs = Cs + a; ICs = ICs + b2; }
+    }
+    const double Cbase = Cs - Cw, ICbase = ICs - ICw;
+    double hiC = __shfl_down(Cs - Cw, 1);  // the next lane's first running weight
+    if (g == NG - 1) hiC = __longlong_as_double(0x7ff0000000000000LL);
+    if (g == NG - 1) sIe[grp][NG] = ICs;   // the last edge is the total weight
+    if (g == 0) sIe[grp][0] = 0.0;
+    // the output edges crossed inside this lane's run of ranks: Cbase < E_k <= hiC
+    int k = 1;
+    while (k < NG && s_E[k] <= Cbase) k++;
+    for (; k < NG; k++) {
+      const double Ek = s_E[k];
+      if (!(Ek <= hiC)) break;
+      double C = Cbase, IC = ICbase, I = -1.0e300;
+#pragma unroll
+      for (int r = 0; r < NG; r++) {
+        I = dmax(I, __builtin_fma(key[r], Ek - C, IC));
+        IC = __builtin_fma(key[r], w[r], IC);
+        C = C + w[r];
+      }
+      sIe[grp][k] = I;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the group's lanes are lanes of this wave
+    tk = (sIe[grp][g + 1] - sIe[grp][g]) * rWg;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the next mixing step rewrites the slots
+  }
+
+  // ---- totals (:856-886)
+  auto store_layer = [&](const int nn, const LayerTerms &T, const double tkv) {
+    const double tau = T.tausg + T.taua + T.taup + tkv + T.tauc;
+    double w0;
+    if (tau <= TAU_MIN) w0 = 0.0;
+    else w0 = fmin(MAX_W0, (T.tausg + T.tausp + T.tausc) / tau);
+    double tb = tau * wg;
+#pragma unroll
+    for (int m = 1; m < NG; m <<= 1) tb = tb + __shfl_xor(tb, m);
+    if (valid) {
+      const size_t o = ((size_t)l * NG + g) * nz + nn;
+      p.tau[o] = tau;
+      p.w0[o] = w0;
+      if (g == 0) {
+        p.tau_band[(size_t)l * nz + nn] = tb;
+        p.g[(size_t)l * nz + nn] = T.gt;
+      }
+    }
+  };
+  store_layer(n, lt, tk);
+  if (__any(pair)) {
+    LayerTerms lt2 = lt;
+    double tk2 = tk;
+    const int j2 = pair ? j + 1 : j;
+    if (pair && !exact) {
+      layer_terms(j2, lt2);
+      if (p.nk == 1) tk2 = k_times_col(0, j2);   // no mixing step to copy: k of the source layer times this layer's own column
+    }
+    const bool keep = valid && pair;
+    // (store_layer shuffles: every lane takes part; lanes without a pair write nothing)
+    const double tau = lt2.tausg + lt2.taua + lt2.taup + tk2 + lt2.tauc;
+    double w0;
+    if (tau <= TAU_MIN) w0 = 0.0;
+    else w0 = fmin(MAX_W0, (lt2.tausg + lt2.tausp + lt2.tausc) / tau);
+    double tb = tau * wg;
+#pragma unroll
+    for (int m = 1; m < NG; m <<= 1) tb = tb + __shfl_xor(tb, m);
+    if (keep) {
+      const size_t o = ((size_t)l * NG + g) * nz + (n - 1);
+      p.tau[o] = tau;
+      p.w0[o] = w0;
+      if (g == 0) {
+        p.tau_band[(size_t)l * nz + (n - 1)] = tb;
+        p.g[(size_t)l * nz + (n - 1)] = lt2.gt;
+      }
+    }
+  }
+}
+
+template <int NG>
+static void launch_coop(const OpacityParams &p, hipStream_t s) {
+  const long lanes = (long)p.nbins * p.nsrc * NG;
+  const int grid = (int)((lanes + OP_THREADS - 1) / OP_THREADS);
+  if (p.cust.on) hipLaunchKernelGGL((k_opacity_coop<NG, true>), dim3(grid), dim3(OP_THREADS), 0, s, p);
+  else hipLaunchKernelGGL((k_opacity_coop<NG, false>), dim3(grid), dim3(OP_THREADS), 0, s, p);
+}
+
 bool launch_opacity(const OpacityParams &p, hipStream_t s) {
   long total = (long)p.nbins * p.nz;
+  if ((p.ng == 16 || p.ng == 32 || (p.ng == 8 && p.coop)) && (long)p.nbins * p.nsrc > 0) {
+    if (p.ng == 8) launch_coop<8>(p, s);
+    else if (p.ng == 16) launch_coop<16>(p, s);
+    else launch_coop<32>(p, s);
+    return true;
+  }
   if (p.ng != 8) {
     if (p.ng < 1 || p.ng > OPG_MAX_NG) return false;
     if (total <= 0) return true;

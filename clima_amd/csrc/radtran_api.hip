@@ -192,6 +192,7 @@ struct Radtran {
   int batch_cols_in_flight = 64;
   bool batch_shared = true;        // radiate_ir_batch: temperature-independent work shared by the columns (CLIMA_HIP_BATCH_SHARED=0: one full solve per column)
   int rebin_mode = 1;              // 0 window form, 1 streaming, 2 streaming multi-edge (rebin_mode_for)
+  long coop_items = 16384;         // ng = 8: at most this many (bin, source layer) items go to k_opacity_coop<8> (CLIMA_HIP_COOP_ITEMS)
   bool fused = true;               // opacity + two-stream in one grid (k_fused); CLIMA_HIP_FUSED=0 or radtran_fused_set turns it off
   DevBuf<int> d_done;              // per opacity block: call id of its last completed run
   int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (id 1) only
@@ -636,11 +637,14 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     op.col = col;
     op.cust = CustomDev{r->d_cust_dtau.p, r->d_cust_w0.p, r->d_cust_g0.p, r->cust_nP, r->nslots, r->cust_on ? 1 : 0};
     op.rebin_mode = r->rebin_mode;
+    // few (bin, source layer) items -- a bin-sharded rank, a short or all-pairs column: the group-of-lanes
+    // kernel (a fifth of the lane-per-item kernel's dependent chain) and one launch per kernel
+    op.coop = (!bc && r->ng == 8 && (long)r->op_n * nsrc <= r->coop_items) ? 1 : 0;
 #ifdef CLIMA_STAMPS
     op.stamps = r->d_stamps.p;
 #endif
     op.tau = o_tau; op.w0 = o_w0; op.g = o_g; op.tau_band = o_tb;
-    if (bc || (r->fused && allow_fused && pre_zeroed)) {
+    if (bc || (r->fused && allow_fused && pre_zeroed && !op.coop)) {
       TwoStreamParams tsf = ts_params();
       if (fused_supported(op, tsf) && pre_zeroed) {
         FusedParams fp;
@@ -1108,6 +1112,14 @@ void radtran_fused_get(void *ptr, int *enabled) {
   Radtran *r = as_rad(ptr);
   *enabled = (r && r->fused) ? 1 : 0;
 }
+void radtran_coop_items_set(void *ptr, const int *items) {
+  Radtran *r = as_rad(ptr);
+  if (r) r->coop_items = *items;
+}
+void radtran_coop_items_get(void *ptr, int *items) {
+  Radtran *r = as_rad(ptr);
+  *items = r ? (int)std::min<long>(r->coop_items, 2147483647L) : 0;
+}
 void radtran_fused_fallbacks_get(void *ptr, int *count) {
   Radtran *r = as_rad(ptr);
   *count = r ? r->fused_fallbacks : 0;
@@ -1225,6 +1237,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   r->d_prep.alloc(r->prep_count); r->d_prep.zero();
   r->d_done.alloc(((size_t)nw * nz + 255) / 256 + 1); r->d_done.zero();
   if (const char *f = getenv("CLIMA_HIP_BATCH_COLS")) r->batch_cols_in_flight = std::max(1, atoi(f));
+  if (const char *f = getenv("CLIMA_HIP_COOP_ITEMS")) r->coop_items = atol(f);
 #ifdef CLIMA_STAMPS
   r->d_stamps.alloc(64 + 2 * 8192); r->d_stamps.zero();
 #endif

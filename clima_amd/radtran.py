@@ -335,6 +335,17 @@ class Radtran:
         self._L.radtran_fused_set(self._ptr, _i(1 if on else 0))
 
     @property
+    def coop_items(self):
+        """ng = 8: calls with at most this many (bin, source layer) items use the group-of-lanes opacity kernel."""
+        v = C.c_int()
+        self._L.radtran_coop_items_get(self._ptr, C.byref(v))
+        return v.value
+
+    @coop_items.setter
+    def coop_items(self, n):
+        self._L.radtran_coop_items_set(self._ptr, _i(int(n)))
+
+    @property
     def fused_fallbacks(self):
         """Calls re-issued through the separate launches after a fused hand-off wait expired."""
         v = C.c_int()

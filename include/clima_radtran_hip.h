@@ -174,6 +174,13 @@ void radtran_set_opacity_labels(void *ptr, const char *k_method, const char *wat
  * 0 = one launch per kernel.  Same results to rounding; CLIMA_HIP_FUSED=0 sets the default off. */
 void radtran_fused_set(void *ptr, const int *enable);
 void radtran_fused_get(void *ptr, int *enabled);
+/* With 8 g-points, calls with at most `items` (bin, source layer) items -- a bin-sharded rank, a short
+ * column -- run the opacity work in the group-of-lanes kernel (8 lanes per item: a fifth of the
+ * dependent chain of the lane-per-item kernel at 2.4x its total work) with one launch per kernel;
+ * larger calls take the lane-per-item kernel inside the fused grid.  Default 16384
+ * (CLIMA_HIP_COOP_ITEMS); 0 turns the group-of-lanes form off.  Same results to rounding (6e-14). */
+void radtran_coop_items_set(void *ptr, const int *items);
+void radtran_coop_items_get(void *ptr, int *items);
 /* A two-stream block of the fused grid waits (bounded) for the opacity blocks of its bin.  If that
  * wait ever expires the call is NOT failed: the library computes it again through the separate
  * launches before results are handed out.  This counts such re-issues on the handle (0 in normal

@@ -100,7 +100,9 @@ def test_bin_sharded_partials_add_up(nominal):
         acc += np.stack([r.wrk_ir.fup_n, r.wrk_ir.fdn_n, r.wrk_sol.fup_n, r.wrk_sol.fdn_n])
     r.set_bin_shard(0, 1)
     assert covered == tb.nw
-    assert np.allclose(acc, full, rtol=1e-12, atol=1e-9)
+    # a quarter of the bins is few enough items for the group-of-lanes opacity kernel (k_opacity_coop<8>),
+    # the whole grid runs the lane-per-item kernel: the two agree to rounding (6e-14 in tau), not bit for bit
+    assert np.allclose(acc, full, rtol=1e-10, atol=1e-9)
 
 
 def test_bin_sharded_ir_only_step_does_not_recount_solar(small_tables):

@@ -78,6 +78,8 @@ def test_random_inventory_and_column(O, seed):
     from test_gpu_parity import TOL_LEVEL
     tb, nz, nzen, albedo, col, scalars, rng = _case(seed)
     r, o = _pair(O, tb, nz, nzen, albedo, **scalars)
+    if seed % 2:
+        r.coop_items = 0    # odd seeds: the lane-per-item opacity kernel (fused grid where it applies); even: k_opacity_coop where the call is small
     surf = None
     if rng.random() < 0.5:   # per-bin surface arrays
         surf = (rng.uniform(0.0, 1.0, len(tb.sol_wavl) - 1), rng.uniform(0.5, 1.0, len(tb.ir_wavl) - 1))

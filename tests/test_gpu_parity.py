@@ -43,6 +43,21 @@ def _pair(O, tables, nz, nzen, albedo, **scalars):
 
 
 def _compare(r, o, col, flux_tol_scale=1.0, **kw):
+    """HIP against the oracle.  With 8 g-points a call of few (bin, layer) items runs the group-of-lanes
+    opacity kernel (k_opacity_coop<8>) and one launch per kernel, a larger one the lane-per-item kernel
+    inside the fused grid: a small test case is therefore compared TWICE, once in each form."""
+    out = _compare_once(r, o, col, flux_tol_scale, **kw)
+    items = r.coop_items
+    if r.ngauss == 8 and items > 0 and r.nw * r.nz <= items and kw.get("compute_opacity", True):
+        r.coop_items = 0
+        try:
+            _compare_once(r, o, col, flux_tol_scale, **kw)
+        finally:
+            r.coop_items = items
+    return out
+
+
+def _compare_once(r, o, col, flux_tol_scale=1.0, **kw):
     """`flux_tol_scale` loosens the flux tolerances for deliberately ill-conditioned settings
     (see test_gpu_fuzz.py); the opacity tolerances never move."""
     f = flux_tol_scale
@@ -354,6 +369,7 @@ def test_fused_and_separate_launch_forms(O, nz, nw, monkeypatch):
     tb = S.modern_earth_tables(nw=nw, seed=31)
     col = S.modern_earth_column(nz)
     r, o = _pair(O, tb, nz, 3, 0.2)
+    r.coop_items = 0      # the lane-per-item opacity kernel, whatever the item count (else small calls take k_opacity_coop)
     assert r.fused
     _compare(r, o, col)
     opr_f = [a.copy() for a in r.opr()]
@@ -366,6 +382,27 @@ def test_fused_and_separate_launch_forms(O, nz, nw, monkeypatch):
     np.testing.assert_allclose(np.array(r.f_total), flux_f, rtol=1e-11, atol=1e-9 * np.max(np.abs(flux_f)))
     monkeypatch.setenv("CLIMA_HIP_FUSED", "0")
     assert not Radtran(tb, nz, 3, 0.2).fused
+
+
+@pytest.mark.parametrize("nz,nw,doubled", [(50, 40, False), (200, 60, False), (13, 7, False), (64, 20, True), (102, 30, True),
+                                            (300, 12, False), (402, 10, True)])
+def test_group_of_lanes_opacity_kernel(O, nz, nw, doubled):
+    # k_opacity_coop<8> (8 lanes per (bin, source layer): cross-lane bitonic sort over ds_swizzle, rebin on
+    # the distributed sorted keys) -- what calls with few items use -- against the oracle and against the
+    # lane-per-item kernel (same opacities to rounding: the running weights are summed in another order)
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=nw, seed=17)
+    col = S.modern_earth_column(nz)
+    if doubled:
+        col = S.doubled_column(S.modern_earth_column(nz // 2))
+    r, o = _pair(O, tb, nz, 3, 0.2)
+    r.coop_items = 1 << 30
+    _compare(r, o, col)
+    opr_c = [a.copy() for a in r.opr()]
+    r.coop_items = 0
+    _compare(r, o, col)
+    for a, b in zip(opr_c, r.opr()):
+        assert _rel(a, b) <= 1e-12
 
 
 def test_fused_handoff_timeout_is_reissued_unfused(O, monkeypatch):
@@ -462,6 +499,7 @@ def test_batched_shared_opacity_ir_calls(O, small_tables, nz, ncol, monkeypatch)
     monkeypatch.setenv("CLIMA_HIP_BATCH_SHARED", "0")
     from clima_amd.radtran import Radtran
     r2 = Radtran(small_tables, nz, 2, 0.3)
+    r2.coop_items = 0      # the opacities resident in `r` are the lane-per-item kernel's (_compare's second pass)
     r2.radiate(*col.args())
     fup2, fdn2, ftot2 = r2.radiate_ir_batch(Ts, T)
     np.testing.assert_array_equal(fup2[:, k3], one_up)
