@@ -1075,12 +1075,28 @@ __global__ __launch_bounds__(64) void k_opacity_generic(OpacityParams p, int N2)
 // form's chain is a fifth of that at 2.4x the total work.
 // Keys carry their pair index in the 2*log2(NG) low mantissa bits (ties ordered as the stable rank).
 // ------------------------------------------------------------------------------------
+// v of lane (lane ^ M), M < 32.  Masks 1, 2, 3 are quad permutations, 7 and 15 the half-row / row mirrors:
+// DPP moves in the VALU; the others go over the LDS crossbar (ds_swizzle, bit-mask mode) -- which is
+// what bounded the 16-g-point kernel when every exchange went that way.
 template <int M>
-__device__ __forceinline__ double swz_xor(double v) {  // v of lane (lane ^ M), M < 32
+__device__ __forceinline__ double swz_xor(double v) {
   const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_ds_swizzle((int)b, (M << 10) | 0x1f);
-  const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), (M << 10) | 0x1f);
+  int lo, hi;
+  constexpr int ctrl = M == 1 ? 0xB1 : M == 2 ? 0x4E : M == 3 ? 0x1B : M == 7 ? 0x141 : M == 15 ? 0x140 : -1;
+  if constexpr (ctrl >= 0) {
+    lo = __builtin_amdgcn_mov_dpp((int)b, ctrl, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), ctrl, 0xf, 0xf, true);
+  } else {
+    lo = __builtin_amdgcn_ds_swizzle((int)b, (M << 10) | 0x1f);
+    hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), (M << 10) | 0x1f);
+  }
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// butterfly sum over the NG lanes of a group
+template <int NG, int M = 1>
+__device__ __forceinline__ double group_sum(double v) {
+  if constexpr (M < NG) return group_sum<NG, 2 * M>(v + swz_xor<M>(v));
+  else return v;
 }
 
 template <int NG>
@@ -1158,13 +1174,17 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
   const double wg = p.wbin[g];
   const double rWg = 1.0 / (s_E[g + 1] - s_E[g]);
 
-  // ---- layer terms (types.f90:665-757): every lane of the group evaluates them (a tenth of the work)
+  // ---- layer terms (types.f90:665-757), shared out over the lanes of the group: lane g takes the
+  //      Rayleigh species and continuum entries g, g+NG, ...; the partial sums meet in a butterfly
+  //      (their order of addition differs from the reference's: rounding only).  Particle and custom
+  //      terms are few and every lane evaluates them.
   auto layer_terms = [&](const int jl, LayerTerms &o) {
     const double dzj = c.dz[jl];
     double tausg = 0.0;
-    for (int i = 0; i < p.nray; i++) tausg = tausg + p.ray[i].data[l] * c.cols[p.ray[i].sp1 * nz + jl];
+    for (int i = g; i < p.nray; i += NG) tausg = tausg + p.ray[i].data[l] * c.cols[p.ray[i].sp1 * nz + jl];
+    tausg = group_sum<NG>(tausg);
     double taua = 0.0;
-    for (int e = 0; e < p.nabs; e++) {
+    for (int e = g; e < p.nabs; e += NG) {
       const AbsEntry &x = p.abs[e];
       double sgm;
       if (x.nT) {
@@ -1177,6 +1197,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
       }
       taua = taua + sgm * c.absw[e * nz + jl];
     }
+    taua = group_sum<NG>(taua);
     double tauc = TINY, tausc = TINY * TINY, g0c = TINY;
     if constexpr (CUSTOM) {
       const int ix = c.ix[p.cust.slot * nz + jl];
@@ -1286,9 +1307,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
     double w0;
     if (tau <= TAU_MIN) w0 = 0.0;
     else w0 = fmin(MAX_W0, (T.tausg + T.tausp + T.tausc) / tau);
-    double tb = tau * wg;
-#pragma unroll
-    for (int m = 1; m < NG; m <<= 1) tb = tb + __shfl_xor(tb, m);
+    const double tb = group_sum<NG>(tau * wg);
     if (valid) {
       const size_t o = ((size_t)l * NG + g) * nz + nn;
       p.tau[o] = tau;
@@ -1314,9 +1333,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
     double w0;
     if (tau <= TAU_MIN) w0 = 0.0;
     else w0 = fmin(MAX_W0, (lt2.tausg + lt2.tausp + lt2.tausc) / tau);
-    double tb = tau * wg;
-#pragma unroll
-    for (int m = 1; m < NG; m <<= 1) tb = tb + __shfl_xor(tb, m);
+    const double tb = group_sum<NG>(tau * wg);
     if (keep) {
       const size_t o = ((size_t)l * NG + g) * nz + (n - 1);
       p.tau[o] = tau;
@@ -2163,10 +2180,18 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       wsum = wsum + wz;
       dir0 = dir0 + wz * u0;
       const double iu2 = iu * iu, wzu = wz * u0;
+#ifdef CLIMA_ZEN_EXP_POLY
+      double et = fexp(-tauc0 * iu);
+#else
       double et = exp_tab(-tauc0 * iu, s_e2);
+#endif
 #pragma unroll
       for (int t = 0; t < L; t++) {
+#ifdef CLIMA_ZEN_EXP_POLY
+        const double etb = et * fexp(-taup[t] * iu);  // :79
+#else
         const double etb = et * exp_tab(-taup[t] * iu, s_e2);  // :79
+#endif
         const double H = zH[t] * (wz * rcp_n1(lam2[t] - iu2));  // (w0/2) * w_z / denom (:80)
         const double sH = __builtin_fma(-zB[t], u0, iu) * H;
         const double XH = zA[t] * H;

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libclima_radtran_hip.so")
+# CLIMA_HIP_LIB: another build of the same library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("CLIMA_HIP_LIB") or os.path.join(_HERE, "csrc", "libclima_radtran_hip.so")
 ERR_LEN = 1024
 
 _dp = C.POINTER(C.c_double)
