@@ -2063,10 +2063,18 @@ struct TsOfs {
   size_t opr, col, res;
 };
 
-template <int L, bool SOLAR, int NZMAX, bool COHERENT, bool RESK>
+// PAIRED: every layer 2m+1 carries the optical properties of layer 2m bit for bit (AdiabatClimate's
+// doubled radiative grid, src/adiabat/clima_adiabat.f90:729-773: the host sets TwoStreamParams::paired
+// when pair_reuse marked every pair as exact).  The lanes' chunks are then cut at pair boundaries, a
+// pair's tau / w0 / g are loaded once, and everything that depends on them alone -- the gammas, lambda,
+// Gamma, exp(-lambda tau), and per zenith angle the attenuation factor and the source factors -- is
+// computed once per pair; the Planck source, the running direct beam and the elimination are per layer
+// as always (same operations on the same values: results are bitwise those of the unpaired form).
+template <int L, bool SOLAR, int NZMAX, bool COHERENT, bool RESK, bool PAIRED = false>
 __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const int bin_local, double *lds,
                                                  const int gy, const int bz, const int tslot = -1,
                                                  const TsOfs co = TsOfs{0, 0, 0}) {
+  static_assert(!PAIRED || (L % 2) == 0, "paired slots come in twos");
 #ifdef CLIMA_STAMPS
 #define TSTAMP(k)                                                                                  \
   do {                                                                                             \
@@ -2104,7 +2112,9 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   const double *w0L = p.w0 + co.opr + ((size_t)l * ng + c) * nz;
   const double *gL = p.g + co.opr + (size_t)l * nz;
   // layers [a,b) TOA-first; slot t holds layer a + t - pad when t >= pad, a zero-thickness layer otherwise
-  const int a = (lane * nz) >> 6, b = ((lane + 1) * nz) >> 6, pad = L - (b - a);
+  const int a = PAIRED ? 2 * ((lane * (nz >> 1)) >> 6) : (lane * nz) >> 6;
+  const int b = PAIRED ? 2 * (((lane + 1) * (nz >> 1)) >> 6) : ((lane + 1) * nz) >> 6;
+  const int pad = L - (b - a);
   const bool is_toa = lane == 0, is_sfc = lane == 63;  // b == nz holds for lane 63 only, and its chunk is never empty
   const double sqrt3 = 1.7320508075688772;
   const double inv_u1 = solar ? sqrt3 : 0.0;  // 1/u1, u1 = 1/sqrt(3) (solar only)
@@ -2113,10 +2123,14 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   double tau_s[L], w0_s[L], gt_s[L];
 #pragma unroll
   for (int t = 0; t < L; t++) {
-    const int i = min(max(a + t - pad, 0), nz - 1);
-    tau_s[t] = ld_opr<COHERENT>(&tauL[i]);
-    w0_s[t] = ld_opr<COHERENT>(&w0L[i]);
-    gt_s[t] = ld_opr<COHERENT>(&gL[i]);
+    if (PAIRED && (t & 1)) {  // the pair's second layer: the same values (pad is even: t-1 is its partner)
+      tau_s[t] = tau_s[t - 1]; w0_s[t] = w0_s[t - 1]; gt_s[t] = gt_s[t - 1];
+    } else {
+      const int i = min(max(a + t - pad, 0), nz - 1);
+      tau_s[t] = ld_opr<COHERENT>(&tauL[i]);
+      w0_s[t] = ld_opr<COHERENT>(&w0L[i]);
+      gt_s[t] = ld_opr<COHERENT>(&gL[i]);
+    }
   }
 #pragma unroll
   for (int t = 0; t < L; t++) {
@@ -2146,6 +2160,12 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     double tauc0 = tcum;
 #pragma unroll
     for (int t = 0; t < L; t++) {
+      if (PAIRED && (t & 1)) {  // the pair's second layer: same tau', w0', g' -> same coefficients
+        G[t] = G[t - 1]; X[t] = X[t - 1]; lam2[t] = lam2[t - 1]; zA[t] = zA[t - 1]; zB[t] = zB[t - 1]; zH[t] = zH[t - 1];
+        tcum = tcum + taup[t];
+        cp0[t] = cm0[t] = cpb[t] = cmb[t] = dir[t] = diru[t] = 0.0;
+        continue;
+      }
       // quotients with denominators of ordinary size: numerator times the correctly rounded
       // reciprocal (6 instructions instead of the 11 of a full division, <= 1 ulp)
       const double w0p = w0_s[t] * (1.0 - gt_s[t] * gt_s[t]) * rcp_nr(1.0 - w0_s[t] * gt_s[t] * gt_s[t]);
@@ -2185,17 +2205,21 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 #else
       double et = exp_tab(-tauc0 * iu, s_e2);
 #endif
+      double ex = 0.0, fp = 0.0, fm = 0.0;  // attenuation and source factors of the current layer (pair)
 #pragma unroll
       for (int t = 0; t < L; t++) {
+        if (!(PAIRED && (t & 1))) {
 #ifdef CLIMA_ZEN_EXP_POLY
-        const double etb = et * fexp(-taup[t] * iu);  // :79
+          ex = fexp(-taup[t] * iu);  // :79
 #else
-        const double etb = et * exp_tab(-taup[t] * iu, s_e2);  // :79
+          ex = exp_tab(-taup[t] * iu, s_e2);  // :79
 #endif
-        const double H = zH[t] * (wz * rcp_n1(lam2[t] - iu2));  // (w0/2) * w_z / denom (:80)
-        const double sH = __builtin_fma(-zB[t], u0, iu) * H;
-        const double XH = zA[t] * H;
-        const double fp = XH - sH, fm = XH + sH;
+          const double H = zH[t] * (wz * rcp_n1(lam2[t] - iu2));  // (w0/2) * w_z / denom (:80)
+          const double sH = __builtin_fma(-zB[t], u0, iu) * H;
+          const double XH = zA[t] * H;
+          fp = XH - sH; fm = XH + sH;
+        }
+        const double etb = et * ex;
         cp0[t] = __builtin_fma(et, fp, cp0[t]);
         cpb[t] = __builtin_fma(etb, fp, cpb[t]);
         cm0[t] = __builtin_fma(et, fm, cm0[t]);
@@ -2235,14 +2259,20 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 #pragma unroll
     for (int s = 0; s <= L; s++) bpl[s] = sB[a + max(s - pad, 0)];
     TSTAMP(1);
+    double r_pair = 0.0;
 #pragma unroll
     for (int t = 0; t < L; t++) {
       const double tau_in = tau_s[t], w0_in = w0_s[t], gt_in = gt_s[t];
-      const double gam1 = 2.0 - w0_in * (1.0 + gt_in);  // :195-201
-      const double gam2 = w0_in * (1.0 - gt_in);
-      const double lam = sqrt_nr(gam1 * gam1 - gam2 * gam2);
-      G[t] = gam2 * rcp_nr(gam1 + lam);
-      X[t] = fexp(-lam * tau_in);
+      if (PAIRED && (t & 1)) {  // the pair's second layer: same tau, w0, g -> same coefficients
+        G[t] = G[t - 1]; X[t] = X[t - 1];
+      } else {
+        const double gam1 = 2.0 - w0_in * (1.0 + gt_in);  // :195-201
+        const double gam2 = w0_in * (1.0 - gt_in);
+        const double lam = sqrt_nr(gam1 * gam1 - gam2 * gam2);
+        G[t] = gam2 * rcp_nr(gam1 + lam);
+        X[t] = fexp(-lam * tau_in);
+        r_pair = rcp_nr(gam1 + gam2);
+      }
       const double bpl_top = bpl[t], bpl_bot = bpl[t + 1];
       double b0n, b1n;  // :216-227 (a zero-thickness slot is thin whatever ir_tau_min is set to)
       if (tau_in <= p.ir_tau_min || t < pad) {
@@ -2253,7 +2283,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
         b1n = (bpl_bot - b0n) / tau_in;
       }
       const double norm = 2.0 * PI * 0.5;
-      const double r = rcp_nr(gam1 + gam2);
+      const double r = r_pair;
       cp0[t] = norm * (b0n + b1n * (r));  // :229-232
       cpb[t] = norm * (b0n + b1n * (tau_in + r));
       cm0[t] = norm * (b0n + b1n * (-r));
@@ -2810,7 +2840,7 @@ bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s) {
 // LSEL = 0: the two-stream part carries the 2-, 3- and 4-slot forms (fp.slots selects); LSEL = 5..8:
 // that one slot count (columns of 257-512 layers), a kernel of its own so that its register needs do
 // not disturb the allocation of the others.
-template <int RM, bool CUSTOM, int LSEL>
+template <int RM, bool CUSTOM, int LSEL, bool PAIRED = false>
 __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoStreamParams ts, FusedParams fp) {
   extern __shared__ __align__(16) double lds[];
   const int per_col = fp.n_op + fp.n_ts;
@@ -2883,7 +2913,15 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   // (fused_supported): their opacity tiles do not fill the machine once, so there is no half-empty
   // second round to fill, and the stand-alone one-slot two-stream kernel runs at five waves per SIMD
   // instead of two.
-  if constexpr (LSEL == 0) {
+  if constexpr (LSEL == 0 && PAIRED) {
+    if (fp.slots == 2) {
+      if (solar) twostream_p_body<2, true, FUSED_NZMAX, true, true, true>(ts, bl, lds, gy, 0, tslot, co);
+      else twostream_p_body<2, false, 0, true, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
+    } else {
+      if (solar) twostream_p_body<4, true, FUSED_NZMAX, true, true, true>(ts, bl, lds, gy, 0, tslot, co);
+      else twostream_p_body<4, false, 0, true, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
+    }
+  } else if constexpr (LSEL == 0) {
     if (fp.slots == 2) {
       if (solar) twostream_p_body<2, true, FUSED_NZMAX, true, true>(ts, bl, lds, gy, 0, tslot, co);
       else twostream_p_body<2, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
@@ -2895,8 +2933,8 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
       else twostream_p_body<4, false, 0, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
     }
   } else {
-    if (solar) twostream_p_body<LSEL, true, FUSED_NZMAX, true, false>(ts, bl, lds, gy, 0, tslot, co);
-    else twostream_p_body<LSEL, false, 0, true, false>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
+    if (solar) twostream_p_body<LSEL, true, FUSED_NZMAX, true, false, PAIRED>(ts, bl, lds, gy, 0, tslot, co);
+    else twostream_p_body<LSEL, false, 0, true, false, PAIRED>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
   }
 #ifdef CLIMA_STAMPS
   __syncthreads();
@@ -2918,6 +2956,15 @@ int fused_tiles(const OpacityParams &op) {
 }
 
 using FusedKern = void (*)(OpacityParams, TwoStreamParams, FusedParams);
+// slots of the paired form: twice the pair slots, ceil((nz/2)/64); 0 when the form does not apply
+static int paired_slots(const OpacityParams &op, const TwoStreamParams &ts) {
+  if (!ts.paired || (ts.nz & 1) || op.rebin_mode != 0 || op.cust.on) return 0;
+  const int s = 2 * ((ts.nz / 2 + 63) / 64);
+  return (s == 2 || s == 4 || s == 6 || s == 8) ? s : 0;
+}
+static FusedKern fused_kernel_paired(int slots) {
+  return slots <= 4 ? (FusedKern)k_fused<0, false, 0, true> : slots == 6 ? (FusedKern)k_fused<0, false, 6, true> : (FusedKern)k_fused<0, false, 8, true>;
+}
 static FusedKern fused_kernel(const OpacityParams &op, int slots) {
   static const FusedKern k04[2][3] = {{k_fused<0, false, 0>, k_fused<1, false, 0>, k_fused<2, false, 0>},
                                       {k_fused<0, true, 0>, k_fused<1, true, 0>, k_fused<2, true, 0>}};
@@ -2934,6 +2981,8 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
   fp.n_op = fused_tiles(op);
   fp.n_ts = nb * groups;
   fp.slots = (ts.nz + 63) / 64;  // 2..8 (fused_supported)
+  const int ps = fp.ncol <= 1 ? paired_slots(op, ts) : 0;   // (a batch's columns are not all pairs)
+  if (ps) fp.slots = ps;
   if (fp.ncol < 1) fp.ncol = 1;
   {
     // solar bins (of this shard) whose opacity tiles sit in the first residency round: two blocks per CU
@@ -2943,7 +2992,7 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
   ts.col_base = 0; ts.accumulate = 1;
   const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)ts.nz + 1);
   const long items = (long)fp.ncol * (fp.n_op + fp.n_ts);
-  const FusedKern k = fused_kernel(op, fp.slots);
+  const FusedKern k = ps ? fused_kernel_paired(ps) : fused_kernel(op, fp.slots);
   if (lds > 48 * 1024 && !ensure_max_lds((const void *)k, 64 * 1024)) return false;  // (the kernel has static LDS too)
   hipLaunchKernelGGL(k, dim3((unsigned)items), dim3(OP_THREADS), lds, s, op, ts, fp);
   return true;

@@ -145,6 +145,7 @@ struct Radtran {
   DevBuf<double> d_col;  // [T_surface | T | P | dz | dens | pdens | radii | meta (ints: nsrc, source list, source of every layer)]
   size_t meta_ofs = 0;   // doubles before the meta ints in a column block
   int nsrc = 0;          // source layers of the resident column (pair_reuse decided at upload)
+  bool all_pairs_exact = false;  // ... and every layer is half of an exact pair (the doubled radiative grid)
   DevBuf<double> d_prep;  // one block: [log10P | cols | foreign_col | absw | q | ix (ints)]
   size_t prep_count = 0;
   std::vector<AbsEntry> abs_entries;  // continuum terms in the reference's summation order
@@ -578,6 +579,9 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     ts.tau = o_tau; ts.w0 = o_w0; ts.g = o_g; ts.tau_band = o_tb;
     ts.ir_fup_a = ir_fup; ts.ir_fdn_a = ir_fdn; ts.ir_tau_band = ir_tb;
     ts.sol_fup_a = sol_fup; ts.sol_fdn_a = sol_fdn; ts.sol_amean = sol_am; ts.sol_tau_band = sol_tb;
+    // exact pairs in the column (and this call computes the opacities from it) -> exact pairs in opr
+    static const bool allow_paired = [] { const char *e = getenv("CLIMA_HIP_PAIRED"); return !(e && e[0] == '0'); }();
+    ts.paired = (allow_paired && !bc && !r->col_override && compute_opacity && r->all_pairs_exact) ? 1 : 0;
     return ts;
   };
   bool pre_zeroed = false, fused_done = false;
@@ -755,7 +759,13 @@ void do_upload(Radtran *r, double T_surface, const double *T, const double *P, c
     std::memcpy(hp + (size_t)nz * r->np, radii, sizeof(double) * (size_t)nz * r->np);
   }
   r->column_has_particles = (pdens && radii);
-  r->nsrc = build_meta(r, T, P, dz, dens, pdens, radii, r->column_has_particles, reinterpret_cast<int *>(h + r->meta_ofs));
+  {
+    int *meta = reinterpret_cast<int *>(h + r->meta_ofs);
+    r->nsrc = build_meta(r, T, P, dz, dens, pdens, radii, r->column_has_particles, meta);
+    bool all = (nz % 2 == 0) && r->nsrc * 2 == nz;
+    for (int m = 0; m < r->nsrc && all; m++) all = (meta[1 + m] & SRC_EXACT) != 0;
+    r->all_pairs_exact = all;
+  }
   {
     // ~18 KB: a kernel that reads the pinned buffer over PCIe gets the column into HBM 4 us sooner
     // than the copy engine does (CLIMA_HIP_COPY_KERNEL=0 selects hipMemcpyAsync)

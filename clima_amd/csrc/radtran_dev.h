@@ -175,6 +175,10 @@ struct TwoStreamParams {
   // instead of computed from T (null in production), and a slot count above ceil(nz/64) (0: none)
   const double *bplanck;
   int force_slots;
+  // every layer 2m+1 (ground-first) carries exactly the optical properties of layer 2m: pair_reuse marked
+  // all pairs as exact copies (AdiabatClimate's doubled radiative grid); the fused grid then takes the
+  // paired form of the two-stream part
+  int paired;
   // IR
   const double *T, *T_surface;
   const double *emissivity;                // [nw_ir]

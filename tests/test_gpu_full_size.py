@@ -259,3 +259,31 @@ def test_config4_1024_perturbed_columns_at_full_size(O, nominal):
             for a in pair:
                 assert np.max(np.abs(fl[:, a, c] - rows[a])) <= 1e-9 * scale, (c, a)
         assert np.max(np.abs(fl[:, 4, c] - rows[4])) <= 1e-9 * np.max(np.abs(rows[4])), c
+
+
+@pytest.mark.parametrize("nz_adiabat,nw", [(50, 700), (100, 400), (150, 260), (200, 200)])
+def test_doubled_radiative_grid_takes_the_paired_two_stream_form(O, nz_adiabat, nw):
+    """AdiabatClimate's radiative grid (copy_atm_to_radiative_grid, src/adiabat/clima_adiabat.f90:729-773:
+    nz_r = 2 nz + 2, every pair of layers identical) with enough bins for the fused grid: the opacity lanes
+    exist per source layer only, and the two-stream part runs in its paired form (2, 4, 6, 8 slots:
+    coefficients computed once per pair).  Against the oracle at the usual tolerances."""
+    from clima_amd import synthetic as S
+    from clima_amd.atmosphere import copy_atm_to_radiative_grid
+    from clima_amd.radtran import Radtran
+    from test_gpu_parity import _compare_once
+    tb = S.modern_earth_tables(nw=nw, seed=5)
+    col = S.Column(copy_atm_to_radiative_grid(S.modern_earth_column(nz_adiabat)))
+    nzr = len(col["T"])
+    assert nzr == 2 * nz_adiabat + 2
+    r = Radtran(tb, nzr, 4, 0.2)
+    assert r.nw * (nzr // 2) > r.coop_items          # the fused grid, not the small-call kernels
+    o = O.OracleRadtran(tb, nzr, 4, 0.2)
+    _compare_once(r, o, col)
+    # the same column with one layer nudged (no longer all pairs): the unpaired form; both agree with the
+    # oracle, and on the unchanged layers with each other to rounding
+    f_pair = np.array(r.f_total)
+    col2 = S.Column(col)
+    col2["T"] = np.array(col["T"], copy=True)
+    col2["T"][nzr // 2] *= 1.0 + 1.0e-9
+    _compare_once(r, o, col2)
+    np.testing.assert_allclose(np.array(r.f_total), f_pair, rtol=1e-6, atol=1e-9 * np.max(np.abs(f_pair)))
