@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <set>
@@ -1518,9 +1519,26 @@ void radtran_radiate_wrapper(void *ptr, const double *T_surface, const int *dim_
                   dim1_r ? *dim1_r : 0, dim2_r ? *dim2_r : 0, hp ? pdensities : nullptr, hp ? radii : nullptr, err))
     return;
   TRY
+#ifdef CLIMA_TRACE_SYNC
+  static double acc[4] = {0, 0, 0, 0};
+  static long ncalls = 0;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+#endif
   do_upload(r, *T_surface, T, P, densities, dz, hp ? pdensities : nullptr, hp ? radii : nullptr);
+#ifdef CLIMA_TRACE_SYNC
+  const double t1 = now();
+#endif
   enqueue_radiate(r, *compute_solar != 0, *compute_opacity != 0);
+#ifdef CLIMA_TRACE_SYNC
+  const double t2 = now();
+#endif
   fetch_small(r);
+#ifdef CLIMA_TRACE_SYNC
+  const double t3 = now();
+  acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; ncalls++;
+  if (ncalls % 100 == 0) { fprintf(stderr, "sync trace over 100 calls: upload %.1f us, enqueue %.1f us, fetch+sync %.1f us\n", acc[0] / 100, acc[1] / 100, acc[2] / 100); acc[0] = acc[1] = acc[2] = 0; }
+#endif
   if (surface_device_error(r, err)) return;
   const int nl = r->nz + 1;
   for (int i = 0; i < nl; i++) r->f_total[i] = r->h_small[4 * nl + i];
