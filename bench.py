@@ -12,9 +12,9 @@ column) are resident in HBM before the timed region starts.
 
 What the one JSON line carries (rank 0):
   value          resident form: K calls enqueued back to back on the handle's stream, bracketed by
-                 barrier + synchronise; the MEDIAN of `--repeats` such K-step timings (a 20-step run
-                 is 2.5 ms: one timing is a sample of the clock ramp), all of them listed in
-                 `repeats_calls_per_s`.
+                 barrier + synchronise; the MEDIAN of at least `--repeats` such K-step timings, and of as
+                 many as it takes to time ~0.3 s in all (a 20-step run is 2.5 ms: one timing is a sample
+                 of the clock ramp); their spread is in `repeats_calls_per_s`.
   sync_api       the drop-in call of SURVEY.md 8(d) "Metric": `radtran_toa_fluxes_wrapper` with host
                  arrays in, ISR / OLR out, one stream synchronise per call (PCIe inclusive); median,
                  p10, p90 over >= 30 calls.  This is what a Fortran / Python caller of `TOA_fluxes`
@@ -194,7 +194,8 @@ def main():
     rad.profile_stride(EVENT_STRIDE)
     rad.profile_reset()
     dts = []
-    for _ in range(max(args.repeats, 1)):
+    repeats = max(args.repeats, 1)
+    while len(dts) < repeats:
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -206,6 +207,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t[0])
         dts.append(dt)
+        if len(dts) == 1:
+            # a short K-step loop (the driver's 20 steps are 2.5 ms) is repeated until ~0.3 s have been timed
+            # in all, so that the median is taken at settled clocks (at most 200 repeats; with N ranks dt is
+            # the all-reduced maximum, the same number on every rank, so all of them loop alike)
+            repeats = max(repeats, min(200, int(0.3 / max(dt, 1e-6)) + 1))
     dt = float(np.median(dts))
     kt_dom = rad.kernel_time(1)
     if kt_dom[1] > 0:
@@ -299,7 +305,9 @@ def main():
                           "parallelism": ("bins sharded over %d GPUs + 1 all-reduce of %d f64" % (world, 4 * (nz + 1)))
                           if world > 1 else "1 GPU"},
                "value_is": "median of %d repeats of the %d-step loop, resident inputs, calls enqueued back to back" % (len(dts), args.steps),
-               "repeats_calls_per_s": [args.steps / x for x in dts],
+               "repeats_calls_per_s": {"n": len(dts), "min": args.steps / max(dts), "p10": args.steps / float(np.percentile(dts, 90)),
+                                       "median": args.steps / dt, "p90": args.steps / float(np.percentile(dts, 10)),
+                                       "max": args.steps / min(dts), "first": args.steps / dts[0]},
                "olr_W_m2": olr / 1e3, "isr_W_m2": isr / 1e3, "roofline": roofline,
                "algorithmic": {"N_PT": nodes["N_PT"], "N_PT_table": nodes["N_PT_full"], "N_T": nodes["N_T"],
                                "N_T_table": nodes["N_T_full"], "bytes_distinct_nodes": b_alg,
