@@ -275,6 +275,34 @@ def test_custom_optical_properties(O, ng):
     assert (isr2, olr2) == (isr0, olr0)
 
 
+@pytest.mark.parametrize("ng", [8, 16, 32])
+def test_group_of_lanes_kernel_pairs_custom_and_single_species(O, ng):
+    # k_opacity_coop<NG> on the paths its one lane per g-point changes: a doubled grid whose pairs are exact
+    # copies (results stored twice), pairs equal only to 1e-13 (the second layer's own terms are evaluated:
+    # types.f90:621-632 compares to 1e-12), custom optical properties, and a single k-species on a doubled
+    # grid (no mixing step to copy: k of the source layer times the second layer's own column, :818)
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=14, ng=ng, seed=23)
+    r, o = _pair(O, tb, 40, 2, 0.25)
+    r.coop_items = 1 << 30
+    col = S.doubled_column(S.modern_earth_column(20))
+    _compare_once(r, o, col)
+    col2 = S.doubled_column(S.modern_earth_column(20))
+    col2["T"][1::2] *= 1 + 1e-13
+    col2["densities"] = np.asfortranarray(col2["densities"])
+    col2["densities"][1::2, 1] *= 1 - 2e-13
+    _compare_once(r, o, col2)
+    args = _custom_props()
+    r.set_custom_optical_properties(*args)
+    o.set_custom_optical_properties(*args)
+    _compare_once(r, o, col2)
+    _compare_once(r, o, S.modern_earth_column(40))
+    tb1 = S.make_tables(nw=10, ng=ng, k_species=("CO2",), seed=6)
+    r1, o1 = _pair(O, tb1, 40, 2, 0.25)
+    r1.coop_items = 1 << 30
+    _compare_once(r1, o1, col2)
+
+
 def test_custom_optical_properties_errors(small_tables):
     from clima_amd.radtran import Radtran, ClimaException
     r = Radtran(small_tables, 10, 1, 0.2)
