@@ -185,42 +185,98 @@ __device__ __forceinline__ double fast_exp(double x, const ExpK &K) {
   return exp_scale(p, k);
 }
 
-// exp(x) for attenuation factors (x <= 0 in exact arithmetic; anything up to ~700 is fine): table form,
-//   x = n*ln2/64 + r,  exp(x) = 2^(n>>6) * 2^((n&63)/64) * exp(r),  |r| <= ln2/128,
-// with the 64 correctly rounded values 2^(i/64) in LDS and a degree-5 polynomial for exp(r) (truncation
-// 3e-17): 16 instructions + one LDS read where fast_exp() takes 23.  <= 1.5 ulp.  Used where a wave
-// evaluates many exponentials whose results are then summed with weights (the zenith-angle loop).
-__device__ const double EXP2_TAB[64] = {
-    1, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
-    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
-    1.0905077326652577, 1.1023825833078409, 1.1143867425958924, 1.1265216186082418,
-    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
-    1.189207115002721, 1.2021567314527031, 1.215247359980469, 1.22848053610687,
-    1.241857812073484, 1.2553807570246911, 1.2690509571917332, 1.2828700160787783,
-    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.3396675240533029,
-    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
-    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
-    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
-    1.5422108254079407, 1.5590044002378369, 1.5759808451078865, 1.593142151342267,
-    1.6104903319492543, 1.6280274218573478, 1.6457554781539649, 1.6636765803267364,
-    1.681792830507429, 1.7001063537185235, 1.7186192981224779, 1.7373338352737062,
-    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
-    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
-    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.9784560263879509};
+// exp(x) for attenuation factors (x <= 0), table form:
+//   f = x*256/ln2,  n = rint(f),  r = f - n (exact, |r| <= 1/2),  exp(x) = 2^(n>>8) * 2^((n&255)/256) * 2^(r/256),
+// with the 256 correctly rounded values 2^(i/256) in LDS and a degree-4 polynomial in r for 2^(r/256)
+// (truncation 4e-17): 14 instructions + one LDS read where fast_exp() takes 23.  The only error beyond
+// ~1 ulp is the rounding of f, |x| * 1.1e-16 relative -- that of an argument known to one rounding, which
+// x (a product) is anyway.  Needs no range clamp: for |f| >= 2^52 r is 0, the conversion of n saturates and
+// the ldexp underflows to 0.  Used where a wave evaluates many exponentials whose results are then summed
+// with weights (the zenith-angle loop); tests/test_gpu_parity.py::test_device_exp_table.
+constexpr int EXP2_N = 256;
+__device__ const double EXP2_TAB[EXP2_N] = {
+    1.0, 1.0027112750502025, 1.0054299011128027, 1.0081558981184175,
+    1.0108892860517005, 1.0136300849514894, 1.016378314910953, 1.019133996077738,
+    1.0218971486541166, 1.0246677928971357, 1.0274459491187637, 1.030231637686041,
+    1.0330248790212284, 1.0358256936019572, 1.0386341019613787, 1.041450124688316,
+    1.0442737824274138, 1.0471050958792898, 1.0499440858006872, 1.0527907730046264,
+    1.0556451783605572, 1.0585073227945128, 1.061377227289262, 1.0642549128844645,
+    1.0671404006768237, 1.0700337118202419, 1.0729348675259756, 1.075843889062791,
+    1.0787607977571199, 1.0816856149932152, 1.0846183622133092, 1.0875590609177697,
+    1.0905077326652577, 1.0934643990728858, 1.0964290818163769, 1.099401802630222,
+    1.102382583307841, 1.1053714457017412, 1.1083684117236787, 1.1113735033448175,
+    1.1143867425958924, 1.1174081515673693, 1.1204377524096067, 1.12347556733302,
+    1.1265216186082418, 1.129575928566288, 1.1326385195987192, 1.1357094141578055,
+    1.1387886347566916, 1.1418762039695616, 1.1449721444318042, 1.148076478840179,
+    1.1511892299529827, 1.154310420590216, 1.1574400736337511, 1.1605782120274988,
+    1.1637248587775775, 1.1668800369524817, 1.1700437696832502, 1.1732160801636373,
+    1.1763969916502812, 1.1795865274628758, 1.182784710984341, 1.1859915656609938,
+    1.189207115002721, 1.1924313825831512, 1.1956643920398273, 1.1989061670743806,
+    1.202156731452703, 1.2054161090051239, 1.2086843236265816, 1.2119613992768012,
+    1.215247359980469, 1.2185422298274085, 1.2218460329727576, 1.2251587936371455,
+    1.22848053610687, 1.2318112847340759, 1.2351510639369334, 1.2384998981998165,
+    1.241857812073484, 1.245224830175258, 1.2486009771892048, 1.2519862778663162,
+    1.255380757024691, 1.2587844395497165, 1.2621973503942507, 1.2656195145788063,
+    1.2690509571917332, 1.2724917033894028, 1.275941778396392, 1.2794012075056693,
+    1.2828700160787783, 1.2863482295460256, 1.2898358734066657, 1.2933329732290895,
+    1.2968395546510096, 1.3003556433796506, 1.3038812651919358, 1.3074164459346773,
+    1.3109612115247644, 1.3145155879493546, 1.318079601266064, 1.3216532776031575,
+    1.3252366431597413, 1.3288297242059544, 1.3324325470831615, 1.3360451382041458,
+    1.339667524053303, 1.3432997311868353, 1.3469417862329458, 1.3505937158920345,
+    1.3542555469368927, 1.3579273062129011, 1.3616090206382248, 1.365300717204012,
+    1.3690024229745905, 1.3727141650876684, 1.3764359707545302, 1.380167867260238,
+    1.383909881963832, 1.387662042298529, 1.3914243757719262, 1.3951969099662003,
+    1.3989796725383112, 1.4027726912202048, 1.4065759938190154, 1.4103896082172707,
+    1.4142135623730951, 1.4180478843204152, 1.4218926021691656, 1.4257477441054942,
+    1.42961333839197, 1.433489413367789, 1.4373759974489824, 1.4412731191286257,
+    1.4451808069770467, 1.449099089642035, 1.4530279958490526, 1.4569675544014438,
+    1.460917794180647, 1.4648787441464057, 1.4688504333369818, 1.4728328908693675,
+    1.4768261459394993, 1.4808302278224719, 1.4848451658727524, 1.488870989524397,
+    1.4929077282912648, 1.4969554117672355, 1.5010140696264256, 1.5050837316234065,
+    1.5091644275934228, 1.5132561874526098, 1.5173590411982147, 1.5214730189088146,
+    1.5255981507445384, 1.529734466947287, 1.533881997840956, 1.5380407738316568,
+    1.5422108254079407, 1.5463921831410214, 1.550584877685, 1.5547889397770887,
+    1.559004400237837, 1.5632312899713576, 1.567469639965553, 1.5717194812923414,
+    1.5759808451078865, 1.5802537626528246, 1.5845382652524937, 1.588834384317164,
+    1.593142151342267, 1.597461597908627, 1.6017927556826934, 1.606135656416771,
+    1.6104903319492543, 1.6148568142048607, 1.6192351351948637, 1.6236253270173289,
+    1.6280274218573478, 1.632441451987275, 1.6368674497669644, 1.6413054476440063,
+    1.645755478153965, 1.6502175739206177, 1.6546917676561943, 1.6591780921616162,
+    1.6636765803267364, 1.6681872651305825, 1.6727101796415966, 1.6772453570178785,
+    1.681792830507429, 1.6863526334483934, 1.6909247992693053, 1.6955093614893326,
+    1.7001063537185235, 1.7047158096580513, 1.709337763100463, 1.713972247929926,
+    1.718619298122478, 1.723278947746274, 1.7279512309618377, 1.732636182022311,
+    1.7373338352737062, 1.7420442251551564, 1.746767386199169, 1.7515033530318782,
+    1.7562521603732995, 1.761013843037584, 1.7657884359332727, 1.7705759740635547,
+    1.7753764925265212, 1.7801900265154245, 1.785016611318935, 1.789856282321401,
+    1.7947090750031072, 1.7995750249405351, 1.804454167806624, 1.809346539371032,
+    1.8142521755003989, 1.8191711121586085, 1.8241033854070534, 1.8290490314048973,
+    1.8340080864093424, 1.8389805867758937, 1.843966568958626, 1.8489660695104508,
+    1.8539791250833855, 1.8590057724288205, 1.864046048397789, 1.8690999899412386,
+    1.8741676341103, 1.8792490180565602, 1.8843441790323345, 1.8894531543909392,
+    1.8945759815869656, 1.8997126981765553, 1.9048633418176741, 1.9100279502703899,
+    1.9152065613971474, 1.9203992131630474, 1.925605943636125, 1.930826790987627,
+    1.9360617934922943, 1.9413109895286405, 1.9465744175792332, 1.9518521162309783,
+    1.9571441241754002, 1.9624504802089273, 1.9677712232331759, 1.9731063922552343,
+    1.978456026387951, 1.9838201648502194, 1.9891988469672663, 1.9945921121709402};
 __device__ __forceinline__ double exp_tab(double x, const double *s_tab) {
-  x = dmax(x, -800.0);  // exp underflows to 0 long before; keeps the reduction below in range
-  const double nf = __builtin_rint(x * 92.33248261689366);    // 64/ln2
-  double r = __builtin_fma(nf, -0.01083042469326756, x);      // ln2/64, leading 32 bits: nf*hi is exact
-  r = __builtin_fma(nf, -2.9815858269852933e-12, r);
+  double f, nf, r;
+  {
+    // (contracted into fma(x, c, -nf), r would be the rounding residual of the product when |f| >= 2^52:
+    // huge, and the result inf instead of 0)
+#pragma clang fp contract(off)
+    f = x * 369.3299304675746;    // 256/ln2
+    nf = __builtin_rint(f);
+    r = f - nf;
+  }
   const int n = (int)nf;
-  const double t = s_tab[n & 63];
-  double p = 8.3333333333333332e-03;
-  p = __builtin_fma(p, r, 4.1666666666666664e-02);
-  p = __builtin_fma(p, r, 1.6666666666666666e-01);
-  p = __builtin_fma(p, r, 0.5);
+  const double t = s_tab[n & (EXP2_N - 1)];
+  double p = 2.239395190875157e-12;              // (ln2/256)^k / k!, k = 4 .. 1
+  p = __builtin_fma(p, r, 3.3083026805413713e-09);
+  p = __builtin_fma(p, r, 3.6655655969101062e-06);
+  p = __builtin_fma(p, r, 0.0027076061740622863);
   p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(t * p, n >> 6);
+  return __builtin_ldexp(t * p, n >> 8);
 }
 // 1/x with one Newton step on v_rcp_f64: relative error <= 2e-15 (tests/devtools/gpu_rcp_accuracy.py),
 // for factors that enter sums of weighted source terms
@@ -404,11 +460,11 @@ __device__ int g_stamp_step = 0;
 // (bin, layer).  x = current mixture tau_k(8), y = new species' k*col (8), in registers.
 // The 64 sums x_i+y_j are sorted by a Batcher odd-even merge network held in registers
 // (one v_min_f64 + one v_max_f64 per compare-exchange).  Each key carries its pair index
-// in the 6 low mantissa bits: that orders ties exactly like the stable rank on
-// (value,index) whenever two values differ above 2^-46 relative, and it is how the sorted
-// stream finds its weight wxy(idx).  The value used downstream is the key with those bits
-// cleared (relative perturbation <= 2^-46 = 1.4e-14, below the 3e-14 that the fast_exp() argument
-// rounding of the k-table interpolation already carries).  When y is ascending (the normal
+// in mantissa bits 3-8 (KEY_IDX_MASK): that orders ties exactly like the stable rank on
+// (value,index) whenever two values differ above 2^-44 relative, and it is how the sorted
+// stream finds its weight wxy(idx).  The value used downstream is the key itself
+// (relative perturbation <= 2^-44 = 5.7e-14, the size of the fast_exp() argument
+// rounding that the k-table interpolation already carries).  When y is ascending (the normal
 // case for k-distributions) the 8 runs of 8 keys are pre-sorted and only the merge tail of
 // the network runs; when x is ascending too (it is, up to rounding, after the first mixing
 // step) the first stage of every merge level is redundant as well: 295 of 543 exchanges.
@@ -447,18 +503,34 @@ constexpr int rb_hi(int k) {
   return TIGHT ? tight[k] : wide[k];
 }
 
+// A sort key carries the index i*8+j of its (x_i, y_j) pair in mantissa bits 3-8 -- as the byte offset
+// of the pair's weight in the LDS table, so that the lookup is one AND and the read (in bits 0-5 it
+// took a shift as well: 64 instructions per mixing step).  The key is the value that enters the
+// integral, so the sum x_i + y_j is perturbed by at most 2^-44 of itself.
+constexpr unsigned long long KEY_IDX_MASK = 0x1f8ULL;
+__device__ __forceinline__ double key_weight(const double key, const double *s_wxy) {
+  const unsigned int off = (unsigned int)__double_as_longlong(key) & (unsigned int)KEY_IDX_MASK;
+  return *(const double *)((const char *)s_wxy + off);
+}
+
 // One straight-line pass serves both tables: the pairs of the tight table always, the pairs that only
 // the wide table holds under a wave-uniform `if (!xys)` per element (two separate unrolled passes
 // behind one branch cost the register allocator 40 spilled registers).
 __device__ __forceinline__ void rebin_window(const double (&key)[64], const bool xys, const double *s_wxy,
-                                             const double (&E)[9], const double (&rW)[8], double (&out)[8]) {
+                                             const double *s_Ew, const double *rW, double (&out)[8]) {
+  // the interior edges, wave-uniform: fetched from LDS for this rebin only (held in vector registers for
+  // the whole tile they cost 18 of them, which were then spilled around the sorts)
+  asm volatile("" ::: "memory");
+  double E[8];
+#pragma unroll
+  for (int k = 1; k < 8; k++) E[k] = s_Ew[k];
   double C = 0.0, IC = 0.0, Ie[9];
 #pragma unroll
   for (int k = 1; k < 8; k++) Ie[k] = -1.0e300;  // below every candidate (the sums are finite)
   constexpr int RB = 8;
   double wn[RB];
 #pragma unroll
-  for (int u = 0; u < RB; u++) wn[u] = s_wxy[(int)((unsigned long long)__double_as_longlong(key[u]) & 63ULL)];
+  for (int u = 0; u < RB; u++) wn[u] = key_weight(key[u], s_wxy);
 #pragma unroll
   for (int pb = 0; pb < 64; pb += RB) {
     double wv[RB];
@@ -467,7 +539,7 @@ __device__ __forceinline__ void rebin_window(const double (&key)[64], const bool
     if (pb + RB < 64) {
 #pragma unroll
       for (int u = 0; u < RB; u++)
-        wn[u] = s_wxy[(int)((unsigned long long)__double_as_longlong(key[pb + RB + u]) & 63ULL)];
+        wn[u] = key_weight(key[pb + RB + u], s_wxy);
     }
 #pragma unroll
     for (int u = 0; u < RB; u++) {
@@ -505,7 +577,7 @@ template <int RM>
 __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y)[8],
                                           double (*sI)[OP_THREADS], const int tid, const int tile,
                                           const double *s_wxy, const double *s_E,
-                                          const double (&E)[9], const double (&rW)[8],
+                                          const double *s_Ew, const double *rW,
                                           double (&out)[8]) {
   double key[64];
   bool ysorted = true, xsorted = true;
@@ -520,7 +592,7 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
     for (int j = 0; j < 8; j++) {
       const double v = x[i] + y[j];  // tau_xy(:, j+(i-1)*ng), types.f90:828
       unsigned long long b = (unsigned long long)__double_as_longlong(v);
-      b = (b & ~63ULL) | (unsigned long long)(i * 8 + j);
+      b = (b & ~KEY_IDX_MASK) | (unsigned long long)((i * 8 + j) << 3);
       key[i * 8 + j] = __longlong_as_double((long long)b);
     }
   }
@@ -569,9 +641,10 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
 #undef CE
   STAMP(g_stamp_buf, 30 + g_stamp_step);
   if constexpr (RM == 0) {
-    rebin_window(key, xys, s_wxy, E, rW, out);
+    rebin_window(key, xys, s_wxy, s_Ew, rW, out);
     return;
   }
+  const double *E = s_Ew;
   constexpr bool MULTI = RM == 2;
   double S = 0.0, c0 = 0.0;
   // Next output edge to pass is E[k]: bk = E[k], `en` points at E[k+1] in the LDS edge table and
@@ -586,7 +659,7 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
   constexpr int RB = 8;
   double wn[RB];
 #pragma unroll
-  for (int u = 0; u < RB; u++) wn[u] = s_wxy[(int)((unsigned long long)__double_as_longlong(key[u]) & 63ULL)];
+  for (int u = 0; u < RB; u++) wn[u] = key_weight(key[u], s_wxy);
 #pragma unroll
   for (int pb = 0; pb < 64; pb += RB) {
     double wv[RB];
@@ -595,11 +668,11 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
     if (pb + RB < 64) {
 #pragma unroll
       for (int u = 0; u < RB; u++)
-        wn[u] = s_wxy[(int)((unsigned long long)__double_as_longlong(key[pb + RB + u]) & 63ULL)];
+        wn[u] = key_weight(key[pb + RB + u], s_wxy);
     }
 #pragma unroll
     for (int u = 0; u < RB; u++) {
-      const double v = key[pb + u];  // value with the pair index in its 6 low bits (<= 63 ulp)
+      const double v = key[pb + u];  // value with the pair index in mantissa bits 3-8 (<= 2^-44 relative)
       const double w = wv[u];
       const double c1 = c0 + w;
       if (c1 > bk) {                    // this element reaches past E[k]
@@ -660,14 +733,14 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   const int tid = threadIdx.x;
   if (tid < NG * NG) s_wxy[tid] = p.wxy[tid];
   if (tid < NG + 4) s_E[tid] = p.wbin_e_pad[tid];
-  double E[NG + 1], wbin[NG];  // wave-uniform: scalar loads
-#pragma unroll
-  for (int k = 0; k < NG + 1; k++) E[k] = p.wbin_e[k];
-#pragma unroll
-  for (int k = 0; k < NG; k++) wbin[k] = p.wbin[k];
-  double rW[NG];
-#pragma unroll
-  for (int k = 0; k < NG; k++) rW[k] = 1.0 / (E[k + 1] - E[k]);
+  // wave-uniform tables read where they are used: the g-point edges E_0..E_8, then the g-point weights
+  __shared__ double s_Ew[2 * NG + 1];
+  if (tid < NG + 1) s_Ew[tid] = p.wbin_e[tid];
+  else if (tid < 2 * NG + 1) s_Ew[tid] = p.wbin[tid - (NG + 1)];
+  // 1/(E_{k+1}-E_k), read at the end of every rebin: wave-uniform values that the compiler kept in (and
+  // spilled from) vector registers across the sorts
+  __shared__ double rW[NG];
+  if (tid < NG) rW[tid] = 1.0 / (p.wbin_e[tid + 1] - p.wbin_e[tid]);
   __syncthreads();
 
 #ifdef CLIMA_STAMPS
@@ -814,7 +887,7 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
       if (tile == 100 && threadIdx.x == 0) { g_stamp_buf = p.stamps; g_stamp_step = s; }
 #endif
       double out[NG];
-      rorr_mix8<RM>(tk, kc, sI, tid, tile, s_wxy, s_E, E, rW, out);
+      rorr_mix8<RM>(tk, kc, sI, tid, tile, s_wxy, s_E, s_Ew, rW, out);
 #pragma unroll
       for (int g = 0; g < NG; g++) tk[g] = out[g];
       STAMP(p.stamps, 4 + 3 * s);
@@ -832,6 +905,8 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
 
   // ---- totals (:856-886)
   auto store_layer = [&](const int nn, const LayerTerms &T, const double (&tkv)[NG]) {
+    asm volatile("" ::: "memory");
+    const double *wbin = s_Ew + NG + 1;
     double tb = 0.0;
     const size_t base = ((size_t)l * NG) * nz + nn;
 #pragma unroll
@@ -1974,12 +2049,15 @@ __device__ __forceinline__ void wscan_build_step(double &a, double &b, const dou
   a = a + b * ta;
   b = b * tb;
 }
+// HALF: two independent scans, lanes 0-31 and 32-63 (the last step, which carries lane 31 into the
+// upper half, is left out)
+template <bool HALF = false>
 __device__ __forceinline__ void wscan_build(double &a, double &b, double *bstep) {
   const double a0 = a, b0 = b;
   wscan_build_step<0>(a, b, a0, b0, bstep); wscan_build_step<1>(a, b, a0, b0, bstep);
   wscan_build_step<2>(a, b, a0, b0, bstep); wscan_build_step<3>(a, b, a0, b0, bstep);
   wscan_build_step<4>(a, b, a0, b0, bstep); wscan_build_step<5>(a, b, a0, b0, bstep);
-  wscan_build_step<6>(a, b, a0, b0, bstep);
+  if constexpr (!HALF) wscan_build_step<6>(a, b, a0, b0, bstep);
 }
 // a-part only, with the multipliers of a previous wscan_build (read through `bs(k)`)
 template <class BS>
@@ -1995,6 +2073,7 @@ __device__ __forceinline__ double wscan_apply(double a, BS bs) {
   return a;
 }
 // inclusive prefix sum over the 64 lanes (same schedule, a-part only with unit multipliers)
+template <bool HALF = false>
 __device__ __forceinline__ double wscan_sum(double a) {
   const double a0 = a;
   a = a + wscan_fetch<0>(0.0, a0, a);
@@ -2003,13 +2082,19 @@ __device__ __forceinline__ double wscan_sum(double a) {
   a = a + wscan_fetch<3>(0.0, a0, a);
   a = a + wscan_fetch<4>(0.0, a0, a);
   a = a + wscan_fetch<5>(0.0, a0, a);
-  a = a + wscan_fetch<6>(0.0, a0, a);
+  if constexpr (!HALF) a = a + wscan_fetch<6>(0.0, a0, a);
   return a;
 }
-// x[lane-1], 0 in lane 0
-__device__ __forceinline__ double wave_shr1(double x) { return dpp_mov<DPP_WAVE_SHR1, 0xf, 0xf>(0.0, x); }
-// x[63-lane]
-__device__ __forceinline__ double wave_reverse(double x) { return __shfl(x, 63 - (int)(threadIdx.x & 63)); }
+// x[lane-1], 0 in lane 0 (HALF: and in lane 32)
+template <bool HALF = false>
+__device__ __forceinline__ double wave_shr1(double x) {
+  const double v = dpp_mov<DPP_WAVE_SHR1, 0xf, 0xf>(0.0, x);
+  if constexpr (HALF) return (threadIdx.x & 31) == 0 ? 0.0 : v;
+  else return v;
+}
+// x[63-lane] (HALF: mirrored within each half)
+template <bool HALF = false>
+__device__ __forceinline__ double wave_reverse(double x) { return __shfl(x, (int)(threadIdx.x & 63) ^ (HALF ? 31 : 63)); }
 
 struct M7 {
   double m00, m02, m10, m11, m12, m20, m22;
@@ -2037,10 +2122,12 @@ __device__ __forceinline__ void m7_scan_step(M7 &P, const M7 &P0) {
   R.m22 = wscan_fetch<STEP>(1.0, P0.m22, P.m22);
   P = m7_mul(P, R);
 }
+template <bool HALF = false>
 __device__ __forceinline__ void m7_prefix_scan(M7 &P) {
   const M7 P0 = P;
   m7_scan_step<0>(P, P0); m7_scan_step<1>(P, P0); m7_scan_step<2>(P, P0); m7_scan_step<3>(P, P0);
-  m7_scan_step<4>(P, P0); m7_scan_step<5>(P, P0); m7_scan_step<6>(P, P0);
+  m7_scan_step<4>(P, P0); m7_scan_step<5>(P, P0);
+  if constexpr (!HALF) m7_scan_step<6>(P, P0);
 }
 
 constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
@@ -2070,11 +2157,19 @@ struct TsOfs {
 // Gamma, exp(-lambda tau), and per zenith angle the attenuation factor and the source factors -- is
 // computed once per pair; the Planck source, the running direct beam and the elimination are per layer
 // as always (same operations on the same values: results are bitwise those of the unpaired form).
-template <int L, bool SOLAR, int NZMAX, bool COHERENT, bool RESK, bool PAIRED = false>
+//
+// HALF: the wave solves TWO g-point columns, one per half of 32 lanes, with L = ceil(nz/32) slots per
+// lane (a block of 4 waves then covers all 8 g-points of a bin).  A column of 200 layers fills 200 of
+// 4 x 64 = 256 slots in the whole-wave form and 400 of 7 x 64 = 448 here, the chunk scans have one
+// step fewer and there are half as many of them -- about a fifth fewer instructions per column.
+template <int L, bool SOLAR, int NZMAX, bool COHERENT, bool RESK, bool PAIRED = false, bool HALF = false>
 __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const int bin_local, double *lds,
                                                  const int gy, const int bz, const int tslot = -1,
                                                  const TsOfs co = TsOfs{0, 0, 0}) {
   static_assert(!PAIRED || (L % 2) == 0, "paired slots come in twos");
+  static_assert(!(PAIRED && HALF), "no paired half-wave form");
+  constexpr int W = HALF ? 32 : 64, WSH = HALF ? 5 : 6;   // lanes per column
+  constexpr int NCOL = TSW_COLS * (HALF ? 2 : 1);          // g-point columns per block
 #ifdef CLIMA_STAMPS
 #define TSTAMP(k)                                                                                  \
   do {                                                                                             \
@@ -2101,10 +2196,11 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     else return planck_fcn(nu, T);
   };
   const int nz = p.nz, ng = p.ng, nl = nz + 1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (W - 1);   // lane within the column's group
+  const int wc = HALF ? (int)(threadIdx.x >> 5) : wave;               // column within the block
   const int ll = (solar ? p.sol_lo : p.ir_lo) + bin_local;
   const int l = (solar ? p.sol_start : p.ir_start) + ll;  // opacity bin (radiate.f90:57)
-  const int c_raw = p.col_base + gy * TSW_COLS + wave;
+  const int c_raw = p.col_base + gy * NCOL + wc;
   const bool col_on = c_raw < ng;
   const int c = col_on ? c_raw : ng - 1;
   const double wcol = col_on ? p.wbin[c] : 0.0;  // g-point weight (radiate.f90:122-126)
@@ -2112,10 +2208,10 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   const double *w0L = p.w0 + co.opr + ((size_t)l * ng + c) * nz;
   const double *gL = p.g + co.opr + (size_t)l * nz;
   // layers [a,b) TOA-first; slot t holds layer a + t - pad when t >= pad, a zero-thickness layer otherwise
-  const int a = PAIRED ? 2 * ((lane * (nz >> 1)) >> 6) : (lane * nz) >> 6;
-  const int b = PAIRED ? 2 * (((lane + 1) * (nz >> 1)) >> 6) : ((lane + 1) * nz) >> 6;
+  const int a = PAIRED ? 2 * ((lane * (nz >> 1)) >> 6) : (lane * nz) >> WSH;
+  const int b = PAIRED ? 2 * (((lane + 1) * (nz >> 1)) >> 6) : ((lane + 1) * nz) >> WSH;
   const int pad = L - (b - a);
-  const bool is_toa = lane == 0, is_sfc = lane == 63;  // b == nz holds for lane 63 only, and its chunk is never empty
+  const bool is_toa = lane == 0, is_sfc = lane == W - 1;  // b == nz holds for the last lane only, and its chunk is never empty
   const double sqrt3 = 1.7320508075688772;
   const double inv_u1 = solar ? sqrt3 : 0.0;  // 1/u1, u1 = 1/sqrt(3) (solar only)
 
@@ -2132,6 +2228,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       gt_s[t] = ld_opr<COHERENT>(&gL[i]);
     }
   }
+  const bool copies_band = gy == 0 && p.col_base == 0 && p.b_out == 0;  // this block copies the band optical depth out
 #pragma unroll
   for (int t = 0; t < L; t++) {
     const bool real = t >= pad;
@@ -2142,13 +2239,25 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 
   double G[L], X[L], cp0[L], cm0[L], cpb[L], cmb[L], dir[L], diru[L];
   double Rsfc, Ssfc = 0.0, lvl0_dn = 0.0, lvl0_am = 0.0;
+  // this column's rows of the block's level values (each lane writes the levels under its own layers)
+  // (level n of column w: lds[(w nl + n) 3 + k], k = 0 up-flux, 1 down-flux, 2 mean intensity.  `mine`
+  // is the entry of the level under the lane's slot 0 -- slot t's is mine[3 t + k], at constant offsets
+  // from ONE per-lane address; it is only dereferenced for t >= pad, where it lies in the lane's range)
+  double *const mine = lds + ((size_t)wc * nl + (a - pad + 1)) * 3;
+  // PARK (5 and more slots per lane): what the zenith-angle loop does not touch waits in LDS instead of
+  // in registers -- Gamma, A and w0/2 of a layer in the lane's own three entries of its level (a
+  // zero-thickness slot has no entry and needs none: its Gamma and w0/2 are 0) -- and the direct beam
+  // goes to the down-flux / mean-intensity entries as soon as it is summed.  With everything in registers the 7-slot
+  // form spilled 25-120 of them to scratch, and every reload stalls the wave for an L2 round trip:
+  // variants with FEWER instructions but more spills ran slower.
+  constexpr bool PARK = SOLAR && (HALF || L >= 5);
 
   if constexpr (solar) {
     // ---- delta-Eddington (:38-40), quadrature coefficients (:43-44), lambda, Gamma (:50-51)
     // exp table of the zenith-angle loop (exp_tab)
-    __shared__ double s_e2[64];
-    if (threadIdx.x < 64) s_e2[threadIdx.x] = EXP2_TAB[threadIdx.x];
-    double taup[L], lam2[L], zA[L], zB[L], zH[L];
+    __shared__ double s_e2[EXP2_N];
+    for (int i = threadIdx.x; i < EXP2_N; i += blockDim.x) s_e2[i] = EXP2_TAB[i];
+    double taup[L], lam[L], zA[L], zB[L], zH[L];
     double tot = 0.0;
 #pragma unroll
     for (int t = 0; t < L; t++) {
@@ -2156,12 +2265,12 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       tot = tot + taup[t];
     }
     // optical depth above the chunk (tauc, :64-67): exclusive wave scan of the chunk totals
-    double tcum = wave_shr1(wscan_sum(tot));  // DPP scans: no LDS round trips (0 enters lane 0)
+    double tcum = wave_shr1<HALF>(wscan_sum<HALF>(tot));  // DPP scans: no LDS round trips (0 enters lane 0)
     double tauc0 = tcum;
 #pragma unroll
     for (int t = 0; t < L; t++) {
       if (PAIRED && (t & 1)) {  // the pair's second layer: same tau', w0', g' -> same coefficients
-        G[t] = G[t - 1]; X[t] = X[t - 1]; lam2[t] = lam2[t - 1]; zA[t] = zA[t - 1]; zB[t] = zB[t - 1]; zH[t] = zH[t - 1];
+        G[t] = G[t - 1]; lam[t] = lam[t - 1]; zA[t] = zA[t - 1]; zB[t] = zB[t - 1]; zH[t] = zH[t - 1];
         tcum = tcum + taup[t];
         cp0[t] = cm0[t] = cpb[t] = cmb[t] = dir[t] = diru[t] = 0.0;
         continue;
@@ -2172,12 +2281,12 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       const double gtp = gt_s[t] * rcp_nr(1.0 + gt_s[t]);
       const double gam1 = sqrt3 * (2.0 - w0p * (1 + gtp)) / 2.0;
       const double gam2 = sqrt3 * w0p * (1.0 - gtp) / 2.0;
-      const double lam = sqrt_nr(gam1 * gam1 - gam2 * gam2);
-      G[t] = gam2 * rcp_nr(gam1 + lam);
-      X[t] = fexp(-lam * taup[t]);  // :56
+      const double lm = sqrt_nr(gam1 * gam1 - gam2 * gam2);
+      G[t] = gam2 * rcp_nr(gam1 + lm);
       // a zero-thickness slot has w0p = 0, so its C+/C- vanish whatever the denominator
-      // lam^2 - 1/u0^2 is -- as long as that is not 0 (u0 = 1/sqrt(3)): keep it away from 0
-      lam2[t] = (t >= pad) ? lam * lam : -1.0;
+      // lam^2 - 1/u0^2 is -- as long as that is not 0 (its lambda is sqrt(3), u0 may be 1/sqrt(3)):
+      // lambda = 0 keeps it at -1/u0^2 (and exp(-lambda tau') = 1 as before: tau' = 0)
+      lam[t] = (t >= pad) ? lm : 0.0;
       // The source factors of :45-46 and :75-77 are affine in u0 and 1/u0:
       //   w0 ((gam1 - 1/u0) gam3 + gam4 gam2) = (w0/2) (A - s),  w0 ((gam1 + 1/u0) gam4 + gam2 gam3) = (w0/2) (A + s),
       //   gam3 = (1 - sqrt3 g u0)/2, gam4 = 1 - gam3,  A = gam1 + gam2 + sqrt3 g,  s = 1/u0 - sqrt3 g (gam2 - gam1) u0:
@@ -2188,6 +2297,11 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       zH[t] = 0.5 * w0p;
       tcum = tcum + taup[t];
       cp0[t] = cm0[t] = cpb[t] = cmb[t] = dir[t] = diru[t] = 0.0;
+    }
+    if constexpr (PARK) {
+#pragma unroll
+      for (int t = 0; t < L; t++)
+        if (t >= pad) { mine[3 * t] = G[t]; mine[3 * t + 1] = zA[t]; mine[3 * t + 2] = zH[t]; }
     }
     __syncthreads();  // s_e2
     TSTAMP(1);
@@ -2205,7 +2319,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 #else
       double et = exp_tab(-tauc0 * iu, s_e2);
 #endif
-      double ex = 0.0, fp = 0.0, fm = 0.0;  // attenuation and source factors of the current layer (pair)
+      double ex = 0.0, R = 0.0, sR = 0.0;  // attenuation and source factors of the current layer (pair)
 #pragma unroll
       for (int t = 0; t < L; t++) {
         if (!(PAIRED && (t & 1))) {
@@ -2214,16 +2328,17 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 #else
           ex = exp_tab(-taup[t] * iu, s_e2);  // :79
 #endif
-          const double H = zH[t] * (wz * rcp_n1(lam2[t] - iu2));  // (w0/2) * w_z / denom (:80)
-          const double sH = __builtin_fma(-zB[t], u0, iu) * H;
-          const double XH = zA[t] * H;
-          fp = XH - sH; fm = XH + sH;
+          R = wz * rcp_n1(__builtin_fma(lam[t], lam[t], -iu2));   // w_z / denom (:80)
+          sR = __builtin_fma(-zB[t], u0, iu) * R;                   // s w_z / denom
         }
+        // C+ = (w0/2) (A - s) e / denom, C- = (w0/2) (A + s) e / denom at the layer's top (e = et) and
+        // bottom (etb): the sums over the angles of e/denom and s e/denom are carried (in cp0 / cm0 and
+        // cpb / cmb), A and w0/2 go on afterwards
         const double etb = et * ex;
-        cp0[t] = __builtin_fma(et, fp, cp0[t]);
-        cpb[t] = __builtin_fma(etb, fp, cpb[t]);
-        cm0[t] = __builtin_fma(et, fm, cm0[t]);
-        cmb[t] = __builtin_fma(etb, fm, cmb[t]);
+        cp0[t] = __builtin_fma(et, R, cp0[t]);
+        cpb[t] = __builtin_fma(etb, R, cpb[t]);
+        cm0[t] = __builtin_fma(et, sR, cm0[t]);
+        cmb[t] = __builtin_fma(etb, sR, cmb[t]);
         dir[t] = __builtin_fma(wzu, etb, dir[t]);   // direct(i+1) = u0*etb (:82)
         diru[t] = __builtin_fma(wz, etb, diru[t]);  // direct(i+1)/u0
         et = etb;
@@ -2238,10 +2353,26 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
         if (z < p.nzen) zen(z);
     }
     for (int z = NZMAX; z < p.nzen; z++) zen(z);
-    lvl0_dn = dir0;   // direct(1) = u0 (:73)
-    lvl0_am = wsum;   // direct(1)/u0 = 1
     Rsfc = p.albedo[ll];
     Ssfc = Rsfc * dir[L - 1];  // :89 (used by the surface row only)
+#pragma unroll
+    for (int t = 0; t < L; t++) {
+      double zAt = zA[t], zHt = zH[t];
+      if constexpr (PARK) {
+        G[t] = 0.0; zAt = 0.0; zHt = 0.0;   // a zero-thickness slot: w0' = 0 -> gamma2 = 0, Gamma = 0 (A: any finite value)
+        if (t >= pad) {
+          G[t] = mine[3 * t]; zAt = mine[3 * t + 1]; zHt = mine[3 * t + 2];
+          mine[3 * t + 1] = dir[t]; mine[3 * t + 2] = diru[t];
+        }
+      }
+      const double a0 = zAt * cp0[t], s0 = cm0[t], ab = zAt * cpb[t], sb = cmb[t];
+      cp0[t] = zHt * (a0 - s0); cm0[t] = zHt * (a0 + s0);
+      cpb[t] = zHt * (ab - sb); cmb[t] = zHt * (ab + sb);
+      if (PAIRED && (t & 1)) X[t] = X[t - 1];
+      else X[t] = fexp(-lam[t] * taup[t]);  // :56
+    }
+    lvl0_dn = dir0;   // direct(1) = u0 (:73)
+    lvl0_am = wsum;   // direct(1)/u0 = 1
   } else {
     Rsfc = p.has_hard_surface ? 1.0 - p.emissivity[ll] : 0.0;  // :186-190
     const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64
@@ -2250,7 +2381,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     const double *Tsfc = p.T_surface + co.col + (size_t)bz * p.b_Ts;
     // Planck source at the levels (radiate.f90:65-69): the same for the block's g-point columns, so
     // each of the nz+1 values is computed once per block instead of L+1 times per lane of every wave
-    double *sB = lds + (size_t)3 * TSW_COLS * nl;
+    double *sB = lds + (size_t)3 * NCOL * nl;
     for (int n = threadIdx.x; n < nl; n += blockDim.x)  // TOA-first level
       sB[n] = p.bplanck ? p.bplanck[n] : planck(avg_freq, n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);
     __syncthreads();
@@ -2280,7 +2411,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
         b1n = 0.0;
       } else {
         b0n = bpl_top;
-        b1n = (bpl_bot - b0n) / tau_in;
+        b1n = (bpl_bot - b0n) * rcp_nr(tau_in);
       }
       const double norm = 2.0 * PI * 0.5;
       const double r = r_pair;
@@ -2369,30 +2500,27 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   //      mirrored across the wave (one LDS permute each), which turns it into a prefix scan that
   //      runs over DPP -- 2 LDS round trips instead of 6, and no participation selects
   M7 P;
-  P.m00 = wave_reverse(uU * dD - uD * dU); P.m02 = wave_reverse(uD); P.m10 = wave_reverse(uU * dS - uS * dU);
-  P.m11 = wave_reverse(uU); P.m12 = wave_reverse(uS); P.m20 = wave_reverse(-dU); P.m22 = 1.0;
-  m7_prefix_scan(P);
+  P.m00 = wave_reverse<HALF>(uU * dD - uD * dU); P.m02 = wave_reverse<HALF>(uD); P.m10 = wave_reverse<HALF>(uU * dS - uS * dU);
+  P.m11 = wave_reverse<HALF>(uU); P.m12 = wave_reverse<HALF>(uS); P.m20 = wave_reverse<HALF>(-dU); P.m22 = 1.0;
+  m7_prefix_scan<HALF>(P);
   TSTAMP(4);
   // P applied to (0,0,1): the state above chunk 63-lane; the state below a chunk is that of the
   // chunk under it, one (mirrored) lane down, and 0 under the last chunk
   const double rinv = rcp_nr(P.m22);
-  const double rho = wave_reverse(wave_shr1(P.m02 * rinv)), sig = wave_reverse(wave_shr1(P.m12 * rinv));
+  const double rho = wave_reverse<HALF>(wave_shr1<HALF>(P.m02 * rinv)), sig = wave_reverse<HALF>(wave_shr1<HALF>(P.m12 * rinv));
   // ---- top-down affine scan: Din_{q+1} = alpha_q + beta_q*Din_q
   const double mm = rcp_nr(1.0 - rho * dU);
   double sa = dS + dU * mm * (rho * dS + sig);
   double sb = dD * (1.0 + dU * mm * rho);
   {
     double bstep[WSCAN_STEPS];
-    wscan_build(sa, sb, bstep);
+    wscan_build<HALF>(sa, sb, bstep);
   }
-  const double Din = wave_shr1(sa);
+  const double Din = wave_shr1<HALF>(sa);
   const double Uin = mm * (rho * dS + sig + rho * dD * Din);
   TSTAMP(5);
 
   // ---- level fluxes (:143-148, :288-293), mean intensity (:135-140), g-point weight
-  double *sFu = lds + (size_t)(0 * TSW_COLS + wave) * nl;
-  double *sFd = lds + (size_t)(1 * TSW_COLS + wave) * nl;
-  double *sAm = lds + (size_t)(2 * TSW_COLS + wave) * nl;
 #pragma unroll
   for (int t = 0; t < L; t++) {
     const int i = a + t - pad;
@@ -2400,39 +2528,51 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     const double y1 = rd[2 * t] + rc[2 * t] * Uin + rl[2 * t] * Din;
     const double y2 = rd[2 * t + 1] + rc[2 * t + 1] * Uin + rl[2 * t + 1] * Din;
     if (t >= pad) {
-      sFu[i + 1] = wcol * (y1 * e.e1 + y2 * e.e2 + cpb[t]);
-      sFd[i + 1] = wcol * ((y1 * e.e3 + y2 * e.e4 + cmb[t]) + dir[t]);
-      sAm[i + 1] = wcol * (inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + cpb[t] + cmb[t]) + diru[t]);
+      const double dir_t = PARK ? mine[3 * t + 1] : dir[t], diru_t = PARK ? mine[3 * t + 2] : diru[t];
+      mine[3 * t] = wcol * (y1 * e.e1 + y2 * e.e2 + cpb[t]);
+      mine[3 * t + 1] = wcol * ((y1 * e.e3 + y2 * e.e4 + cmb[t]) + dir_t);
+      mine[3 * t + 2] = wcol * (inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + cpb[t] + cmb[t]) + diru_t);
       if (i == 0) {
         const double top = (y1 * e.e3 - y2 * e.e4) + cp0[t];
-        sFu[0] = wcol * top;
-        sFd[0] = wcol * lvl0_dn;
-        sAm[0] = wcol * (inv_u1 * top + lvl0_am);
+        double *lv0 = lds + (size_t)wc * nl * 3;
+        lv0[0] = wcol * top;
+        lv0[1] = wcol * lvl0_dn;
+        lv0[2] = wcol * (inv_u1 * top + lvl0_am);
       }
     }
   }
   TSTAMP(6);
+  // What the last lines need from memory -- the bin's unit factors and the band optical depth this block
+  // copies out (a device-scope load, as slow as the first ones) -- is requested HERE, neither earlier (held
+  // in registers through the solve they were spilled, and a scratch reload takes as long as the load) nor
+  // later (after the barrier the wave would sit through the whole latency)
+  asm volatile("" ::: "memory");
+  double scale = 1.0, amf = 1.0, band_tau = 0.0;
+  if (solar) {
+    scale = p.photons_sol[ll] * p.photon_scale_factor;  // clima_radtran.f90:302
+    amf = p.am_f1[ll];
+  }
+  const double amf2 = solar ? p.am_f2[ll] : 1.0, amdw = solar ? p.am_dw[ll] : 1.0;
+  if (copies_band && (int)threadIdx.x < nz) band_tau = ld_opr<COHERENT>(&p.tau_band[co.opr + (size_t)l * nz + (nz - 1 - (int)threadIdx.x)]);
   __syncthreads();
   TSTAMP(7);
   // ---- sum over the block's g-points, unit factors (radiate.f90:167-180), reversal (:140-154)
   const bool split = p.accumulate != 0;
-  double scale = 1.0;
-  if (solar) scale = p.photons_sol[ll] * p.photon_scale_factor;  // clima_radtran.f90:302
   for (int n = threadIdx.x; n < nl; n += blockDim.x) {
     double fu = 0.0, fd = 0.0, am = 0.0;
 #pragma unroll
-    for (int w = 0; w < TSW_COLS; w++) {
-      fu = fu + lds[(size_t)(0 * TSW_COLS + w) * nl + n];
-      fd = fd + lds[(size_t)(1 * TSW_COLS + w) * nl + n];
-      am = am + lds[(size_t)(2 * TSW_COLS + w) * nl + n];
+    for (int w = 0; w < NCOL; w++) {
+      fu = fu + lds[((size_t)w * nl + n) * 3];
+      fd = fd + lds[((size_t)w * nl + n) * 3 + 1];
+      am = am + lds[((size_t)w * nl + n) * 3 + 2];
     }
     const size_t o = co.res + (size_t)ll * nl + (nz - n);
     if (solar) {
       fu = fu * scale * p.diurnal_fac;
       fd = fd * scale * p.diurnal_fac;
       am = am * scale * p.diurnal_fac;
-      am = am * p.am_f1[ll];
-      am = am * p.am_f2[ll] * p.am_dw[ll];
+      am = am * amf;
+      am = am * amf2 * amdw;
       if (split) { atomicAdd(&p.sol_fup_a[o], fu); atomicAdd(&p.sol_fdn_a[o], fd); atomicAdd(&p.sol_amean[o], am); }
       else { p.sol_fup_a[o] = fu; p.sol_fdn_a[o] = fd; p.sol_amean[o] = am; }
     } else {
@@ -2441,9 +2581,10 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       else { p.ir_fup_a[ob] = fu; p.ir_fdn_a[ob] = fd; }
     }
   }
-  if (gy == 0 && p.col_base == 0 && p.b_out == 0) {
+  if (copies_band) {
     double *tb = (solar ? p.sol_tau_band : p.ir_tau_band) + co.res;
-    for (int i = threadIdx.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = ld_opr<COHERENT>(&p.tau_band[co.opr + (size_t)l * nz + (nz - 1 - i)]);
+    if ((int)threadIdx.x < nz) tb[(size_t)ll * nz + threadIdx.x] = band_tau;
+    for (int i = threadIdx.x + blockDim.x; i < nz; i += blockDim.x) tb[(size_t)ll * nz + i] = ld_opr<COHERENT>(&p.tau_band[co.opr + (size_t)l * nz + (nz - 1 - i)]);
   }
   TSTAMP(8);
 #undef TSTAMP
@@ -2455,7 +2596,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 // the second wave
 template <int LMAX>
 __global__ __launch_bounds__(64 * TSW_COLS, LMAX > 4 ? 2 : 1) void k_twostream_w(TwoStreamParams p) {
-  extern __shared__ __align__(16) double lds[];  // [3][TSW_COLS][nz+1] weighted level values
+  extern __shared__ __align__(16) double lds[];  // [TSW_COLS][nz+1][3] weighted level values, then the Planck table
   if ((int)blockIdx.x < p.n_sol) twostream_p_body<LMAX, true, 0, false, false>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
   else twostream_p_body<LMAX, false, 0, false, false>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
 }
@@ -2840,7 +2981,9 @@ bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s) {
 // LSEL = 0: the two-stream part carries the 2-, 3- and 4-slot forms (fp.slots selects); LSEL = 5..8:
 // that one slot count (columns of 257-512 layers), a kernel of its own so that its register needs do
 // not disturb the allocation of the others.
-template <int RM, bool CUSTOM, int LSEL, bool PAIRED = false>
+// HALF: the two-stream items are one block per bin, its waves solving two g-point columns each
+// (twostream_p_body's half-wave form) with LSEL = ceil(nz/32) slots per lane.
+template <int RM, bool CUSTOM, int LSEL, bool PAIRED = false, bool HALF = false>
 __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoStreamParams ts, FusedParams fp) {
   extern __shared__ __align__(16) double lds[];
   const int per_col = fp.n_op + fp.n_ts;
@@ -2870,11 +3013,16 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
     // not out yet holds its slot while it waits; in plain (group, channel, bin) order the late solar
     // bins of group 0 sat in front of ready IR work (-0.8 us per call).
     const int nS = ts.n_sol, nI = ts.n_ir, E = fp.sol_early, Lt = nS - E;
-    const int seg[6] = {E, E, nI, nI, Lt, Lt};
-    int r = b, k = 0;
-    while (k < 5 && r >= seg[k]) { r -= seg[k]; k++; }
-    gy = k & 1;
-    bl = k < 2 ? r : k < 4 ? nS + r : E + r;
+    if constexpr (HALF) {   // one group: early solar, IR, late solar
+      gy = 0;
+      bl = b < E ? b : b < E + nI ? nS + (b - E) : b - nI;
+    } else {
+      const int seg[6] = {E, E, nI, nI, Lt, Lt};
+      int r = b, k = 0;
+      while (k < 5 && r >= seg[k]) { r -= seg[k]; k++; }
+      gy = k & 1;
+      bl = k < 2 ? r : k < 4 ? nS + r : E + r;
+    }
   }
   const bool solar = bl < ts.n_sol;
   const int ll = solar ? ts.sol_lo + bl : ts.ir_lo + (bl - ts.n_sol);
@@ -2889,6 +3037,9 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
     const int d0 = max((int)(t0 / OP_THREADS), 0), d1 = min((int)((t0 + nsrc - 1) / OP_THREADS), fp.n_op - 1);
     const int *done = fp.done + (size_t)cb * fp.bs.done;
     int ok = 1;
+    // the usual case is one or two tiles: both flags are fetched before either is looked at (one round
+    // trip to the device-coherent level instead of two)
+    int spins = 0;
     for (int d = d0; d <= d1 && ok; d++) {
       int spins = 0;
       while (__hip_atomic_load(&done[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fp.call_id) {
@@ -2903,7 +3054,9 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   if (!s_ok) return;
 #ifdef CLIMA_STAMPS
   if (op.stamps && threadIdx.x == 0 && cb == 0) op.stamps[64 + 2 * 3128 + 3 * b + 1] = __builtin_amdgcn_s_memrealtime();
-  const int tslot = (b == 1500) ? 32 : (b == 2200 ? 48 : -1);  // two blocks of the two-stream-only tail
+  // two blocks whose phases are stamped: late ones of the whole-wave form; a solar and an IR one of the half-wave form
+  const int tslot = HALF ? (b == fp.sol_early / 2 ? 32 : (b == fp.sol_early + ts.n_ir / 2 ? 48 : -1))
+                         : (b == 1500) ? 32 : (b == 2200 ? 48 : -1);
 #else
   const int tslot = -1;
 #endif
@@ -2913,7 +3066,10 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   // (fused_supported): their opacity tiles do not fill the machine once, so there is no half-empty
   // second round to fill, and the stand-alone one-slot two-stream kernel runs at five waves per SIMD
   // instead of two.
-  if constexpr (LSEL == 0 && PAIRED) {
+  if constexpr (HALF) {
+    if (solar) twostream_p_body<LSEL, true, FUSED_NZMAX, true, false, false, true>(ts, bl, lds, gy, 0, tslot, co);
+    else twostream_p_body<LSEL, false, 0, true, false, false, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
+  } else if constexpr (LSEL == 0 && PAIRED) {
     if (fp.slots == 2) {
       if (solar) twostream_p_body<2, true, FUSED_NZMAX, true, true, true>(ts, bl, lds, gy, 0, tslot, co);
       else twostream_p_body<2, false, 0, true, true, true>(ts, bl - ts.n_sol, lds, gy, 0, tslot, co);
@@ -2965,6 +3121,15 @@ static int paired_slots(const OpacityParams &op, const TwoStreamParams &ts) {
 static FusedKern fused_kernel_paired(int slots) {
   return slots <= 4 ? (FusedKern)k_fused<0, false, 0, true> : slots == 6 ? (FusedKern)k_fused<0, false, 6, true> : (FusedKern)k_fused<0, false, 8, true>;
 }
+// slots per lane of the half-wave two-stream form, ceil(nz/32); 0 when the form does not apply
+// (CLIMA_HIP_NO_HALF=1 switches it off: the A/B switch of tools/gpu_ab.sh)
+static int half_slots(const OpacityParams &op, const TwoStreamParams &ts) {
+  static const bool off = [] { const char *e = getenv("CLIMA_HIP_NO_HALF"); return e && e[0] == '1'; }();
+  if (off || ts.ng != 8 || op.rebin_mode != 0 || op.cust.on) return 0;
+  const int s = (ts.nz + 31) / 32;
+  return s == 7 ? s : 0;
+}
+static FusedKern fused_kernel_half(int slots) { (void)slots; return (FusedKern)k_fused<0, false, 7, false, true>; }
 static FusedKern fused_kernel(const OpacityParams &op, int slots) {
   static const FusedKern k04[2][3] = {{k_fused<0, false, 0>, k_fused<1, false, 0>, k_fused<2, false, 0>},
                                       {k_fused<0, true, 0>, k_fused<1, true, 0>, k_fused<2, true, 0>}};
@@ -2983,23 +3148,26 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
   fp.slots = (ts.nz + 63) / 64;  // 2..8 (fused_supported)
   const int ps = fp.ncol <= 1 ? paired_slots(op, ts) : 0;   // (a batch's columns are not all pairs)
   if (ps) fp.slots = ps;
+  const int hs = ps ? 0 : half_slots(op, ts);
+  if (hs) { fp.slots = hs; fp.n_ts = nb; }
   if (fp.ncol < 1) fp.ncol = 1;
   {
     // solar bins (of this shard) whose opacity tiles sit in the first residency round: two blocks per CU
     const long first_round_bins = ((long)2 * device_cus() * OP_THREADS) / std::max(op.nsrc, 1);
     fp.sol_early = (int)std::min<long>(ts.n_sol, std::max<long>(0, first_round_bins - (long)(ts.sol_start + ts.sol_lo - op.bin_lo)));
   }
-  ts.col_base = 0; ts.accumulate = 1;
-  const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)ts.nz + 1);
+  ts.col_base = 0; ts.accumulate = hs ? 0 : 1;   // (a half-wave block holds all 8 g-points of its bin)
+  const size_t lds = sizeof(double) * (3 * TSW_COLS * (hs ? 2 : 1) + 1) * ((size_t)ts.nz + 1);
   const long items = (long)fp.ncol * (fp.n_op + fp.n_ts);
-  const FusedKern k = ps ? fused_kernel_paired(ps) : fused_kernel(op, fp.slots);
+  const FusedKern k = ps ? fused_kernel_paired(ps) : hs ? fused_kernel_half(hs) : fused_kernel(op, fp.slots);
   if (lds > 48 * 1024 && !ensure_max_lds((const void *)k, 64 * 1024)) return false;  // (the kernel has static LDS too)
   hipLaunchKernelGGL(k, dim3((unsigned)items), dim3(OP_THREADS), lds, s, op, ts, fp);
   return true;
 }
 
-bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s) {
+bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s, bool half) {
   if (ts.ng != 8 || slots < 2 || slots > 8 || (ts.nz + 63) / 64 > slots || ts.nzen > MAX_ZEN) return false;
+  if (half && (slots != 7 || (ts.nz + 31) / 32 > slots)) return false;
   OpacityParams op;
   memset(&op, 0, sizeof(op));
   op.nz = ts.nz;
@@ -3008,12 +3176,12 @@ bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta
   memset(&fp, 0, sizeof(fp));
   fp.ncol = 1;
   fp.n_op = 0;        // no opacity tiles: the two-stream blocks have nothing to wait for
-  fp.n_ts = (ts.n_sol + ts.n_ir) * ((ts.ng + TSW_COLS - 1) / TSW_COLS);
+  fp.n_ts = (ts.n_sol + ts.n_ir) * (half ? 1 : (ts.ng + TSW_COLS - 1) / TSW_COLS);
   fp.slots = slots;
   fp.sol_early = ts.n_sol;
-  ts.col_base = 0; ts.accumulate = 1;
-  const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)ts.nz + 1);
-  const FusedKern k = fused_kernel(op, slots);
+  ts.col_base = 0; ts.accumulate = half ? 0 : 1;
+  const size_t lds = sizeof(double) * (3 * TSW_COLS * (half ? 2 : 1) + 1) * ((size_t)ts.nz + 1);
+  const FusedKern k = half ? fused_kernel_half(slots) : fused_kernel(op, slots);
   if (lds > 48 * 1024 && !ensure_max_lds((const void *)k, 64 * 1024)) return false;
   hipLaunchKernelGGL(k, dim3(fp.n_ts), dim3(OP_THREADS), lds, s, op, ts, fp);
   return true;
@@ -3226,6 +3394,16 @@ void launch_test_rcp(const double *x, double *y, int n, hipStream_t s) {
 }
 void launch_test_exp(const double *x, double *y, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_test_exp, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
+}
+__global__ __launch_bounds__(256) void k_test_exp_tab(const double *x, double *y, int n) {
+  __shared__ double s_e2[EXP2_N];
+  for (int i = threadIdx.x; i < EXP2_N; i += blockDim.x) s_e2[i] = EXP2_TAB[i];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = exp_tab(x[i], s_e2);
+}
+void launch_test_exp_tab(const double *x, double *y, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_test_exp_tab, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
 }
 
 __global__ void k_copy(double *dst, const double *src, size_t n) {

@@ -1774,6 +1774,19 @@ void clima_test_device_exp(const int *n, const double *x, double *y, char *err) 
   CATCH(err)
 }
 
+// the table exp of the zenith-angle loop (arguments <= 0)
+void clima_test_device_exp_table(const int *n, const double *x, double *y, char *err) {
+  clear_err(err);
+  TRY
+  DevBuf<double> dx, dy;
+  dx.alloc(*n); dy.alloc(*n);
+  HIPCHK(hipMemcpy(dx.p, x, sizeof(double) * *n, hipMemcpyHostToDevice));
+  launch_test_exp_tab(dx.p, dy.p, *n, nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(y, dy.p, sizeof(double) * *n, hipMemcpyDeviceToHost));
+  CATCH(err)
+}
+
 void clima_test_device_rcp(const int *n, const double *x, double *y, char *err) {
   clear_err(err);
   TRY
@@ -1855,9 +1868,9 @@ void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, cons
   size_t lds = 0;
   if (*form == 0) ok = launch_twostream_w(ts, nullptr, &lds, false);
   else if (*form == 1) ok = launch_twostream(ts, nullptr, &lds);
-  else if (*form == 2) {
+  else if (*form == 2 || *form == 4) {   // 4: the half-wave form (two g-point columns per wave)
     d_qm.upload(std::vector<int>{nz});  // the column's source-layer count
-    ok = launch_fused_twostream_only(ts, *slots, d_qm.p, nullptr);
+    ok = launch_fused_twostream_only(ts, *slots, d_qm.p, nullptr, *form == 4);
   }
   else if (*form == 3) { ts.b_T = 0; ts.b_Ts = 0; ts.b_out = 0; ok = launch_twostream_ir_batch(ts, 1, nullptr); }
   HIPCHK(hipGetLastError());

@@ -253,7 +253,7 @@ int fused_tiles(const OpacityParams &op);   // opacity tiles per column (size of
 bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s);
 // test hook: the two-stream blocks of the fused grid alone (no opacity blocks), on opacities already in HBM
 // (meta_nsrc: a device int, any value >= 1)
-bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s);
+bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s, bool half = false);
 int twostream_w_groups(int ng);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
 void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t s);
@@ -264,5 +264,6 @@ void launch_copy(double *dst, const double *src, size_t n, hipStream_t s);  // s
 void launch_test_rcp(const double *x, double *y, int n, hipStream_t s);
 void launch_test_wscan(const double *a, const double *b, double *out, int nwaves, hipStream_t s);
 void launch_test_exp(const double *x, double *y, int n, hipStream_t s);
+void launch_test_exp_tab(const double *x, double *y, int n, hipStream_t s);
 
 }  // namespace clima

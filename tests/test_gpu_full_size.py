@@ -40,7 +40,9 @@ def test_solar_is_linear_in_the_stellar_flux(nominal):
     r.radiate(*col.args(), compute_opacity=False)
     assert np.allclose(r.wrk_sol.fup_n, 0.25 * base_up, rtol=1e-13)
     assert np.allclose(r.wrk_sol.fdn_n, 0.25 * base_dn, rtol=1e-13)
-    assert np.array_equal(r.wrk_ir.fup_n, ir_up)           # the IR does not see the star
+    # the IR does not see the star (to rounding: the call without the opacity step takes the stand-alone
+    # two-stream kernel, whose lanes cut the column into other chunks than the fused grid's)
+    assert np.allclose(r.wrk_ir.fup_n, ir_up, rtol=1e-12, atol=0.0)
     r.photon_scale_factor = 1.0
 
 

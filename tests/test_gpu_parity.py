@@ -114,6 +114,28 @@ def test_device_exp(hip_lib):
     assert np.all(np.abs(y[~normal & (ref > 0) & np.isfinite(ref)] - ref[~normal & (ref > 0) & np.isfinite(ref)]) <= 1e-300)
 
 
+def test_device_exp_table(hip_lib):
+    """The table exp of the solar zenith-angle loop (arguments <= 0): within 1.5 ulp + |x| * 2^-53 relative
+    (the second term is the rounding of the scaled argument), 0 for anything below the underflow limit."""
+    import ctypes as C
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-745, 0, 200000), -10 ** rng.uniform(-14, 3, 50000), rng.uniform(-1e-2, 0, 5000),
+                        [0.0, -0.0, -745.2, -800.0, -1e6, -1e9, -2.3e7, -1e14, -1e300, -np.log(2) / 256, -np.log(2) / 512]])
+    y = np.empty_like(x)
+    err = C.create_string_buffer(1025)
+    dp = C.POINTER(C.c_double)
+    hip_lib.clima_test_device_exp_table(C.byref(C.c_int(len(x))), x.ctypes.data_as(dp), y.ctypes.data_as(dp), err)
+    assert err.value == b""
+    with np.errstate(under="ignore"):
+        ref = np.exp(x)
+    normal = ref > 1e-300
+    rel = np.abs(y[normal] - ref[normal]) / ref[normal]
+    assert np.all(rel <= (1.5 + np.abs(x[normal])) * 2.0 ** -52), (rel / ((1.5 + np.abs(x[normal])) * 2.0 ** -52)).max()
+    assert np.all(y[ref == 0.0] == 0.0)
+    assert np.all(np.abs(y[~normal] - ref[~normal]) <= 1e-300)
+    assert y[-11] == 1.0 and y[-10] == 1.0        # exp(0), exp(-0)
+
+
 def test_device_rcp_and_sqrt(hip_lib):
     """The kernels' reciprocal (v_rcp_f64 + 2 Newton steps) and square root (v_rsq_f64 + Goldschmidt),
     used where the reference divides or calls sqrt on quantities of ordinary size: <= 1 ulp."""

@@ -36,7 +36,7 @@ for x in np.arange(0, max(w[:, 1].max(), t[:, 2].max()) + 5, 5.0):
     tr = int(((t[:, 1] <= x) & (t[:, 2] > x)).sum())
     print("  %5.0f  %6d  %6d  %6d" % (x, ow, tw, tr))
 names = ["", "setup (solar: tcum scan)", "coefficients + elimination", "upward sweep + affine map", "M7 suffix scan", "prefix scan + boundary", "level fluxes -> LDS", "barrier", "g-point sum + atomics"]
-for label, base in (("two-stream block 1500", 32), ("two-stream block 2200", 48)):
+for label, base in (("stamped two-stream block A (whole-wave form: 1500; half-wave: a solar one)", 32), ("stamped two-stream block B (2200; an IR one)", 48)):
     v = s[base:base + 9].astype(float)
     if v[8] <= 0: continue
     print(label, "total %.0f cycles" % (v[8] - v[0]))
