@@ -2250,7 +2250,10 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   // goes to the down-flux / mean-intensity entries as soon as it is summed.  With everything in registers the 7-slot
   // form spilled 25-120 of them to scratch, and every reload stalls the wave for an L2 round trip:
   // variants with FEWER instructions but more spills ran slower.
-  constexpr bool PARK = SOLAR && (HALF || L >= 5);
+  // Both channels: the source terms at the layers' lower faces (C+(tau), and in the IR C-(tau): the
+  // solar down-flux and mean-intensity entries hold the direct beam), which the elimination reads for the
+  // last time long before the level fluxes need them again, wait there through the scans.
+  constexpr bool PARK = HALF || L >= 5;
 
   if constexpr (solar) {
     // ---- delta-Eddington (:38-40), quadrature coefficients (:43-44), lambda, Gamma (:50-51)
@@ -2368,6 +2371,9 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       const double a0 = zAt * cp0[t], s0 = cm0[t], ab = zAt * cpb[t], sb = cmb[t];
       cp0[t] = zHt * (a0 - s0); cm0[t] = zHt * (a0 + s0);
       cpb[t] = zHt * (ab - sb); cmb[t] = zHt * (ab + sb);
+      if constexpr (PARK) {
+        if (t >= pad) mine[3 * t] = cpb[t];
+      }
       if (PAIRED && (t & 1)) X[t] = X[t - 1];
       else X[t] = fexp(-lam[t] * taup[t]);  // :56
     }
@@ -2420,6 +2426,9 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       cm0[t] = norm * (b0n + b1n * (-r));
       cmb[t] = norm * (b0n + b1n * (tau_in - r));
       dir[t] = diru[t] = 0.0;
+      if constexpr (PARK) {
+        if (t >= pad) { mine[3 * t] = cpb[t]; mine[3 * t + 1] = cmb[t]; }
+      }
     }
     {  // surface source (:236-247), used by the surface row only
       const double tau_in = tau_s[L - 1], bpl_top = bpl[L - 1], bpl_bot = bpl[L];
@@ -2437,6 +2446,10 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   //      Row 2t-1 couples slots t-1,t (Fortran even rows, :106-112), row 2t likewise (odd rows,
   //      :97-103); row 0 and row 2L-1 are the flux boundary rows (TOA :93-96 / surface :113-117 at
   //      the column ends).
+  // C+(0) of the lane's first real layer (the column top's source in lane 0: the last lines use it)
+  double cp0_top = cp0[0];
+#pragma unroll
+  for (int t = 1; t < L; t++) cp0_top = (t == pad) ? cp0[t] : cp0_top;
   double rc[2 * L], rd[2 * L], rl[2 * L];
   {
     double cp, dp, lp;
@@ -2528,12 +2541,17 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     const double y1 = rd[2 * t] + rc[2 * t] * Uin + rl[2 * t] * Din;
     const double y2 = rd[2 * t + 1] + rc[2 * t + 1] * Uin + rl[2 * t + 1] * Din;
     if (t >= pad) {
-      const double dir_t = PARK ? mine[3 * t + 1] : dir[t], diru_t = PARK ? mine[3 * t + 2] : diru[t];
-      mine[3 * t] = wcol * (y1 * e.e1 + y2 * e.e2 + cpb[t]);
-      mine[3 * t + 1] = wcol * ((y1 * e.e3 + y2 * e.e4 + cmb[t]) + dir_t);
-      mine[3 * t + 2] = wcol * (inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + cpb[t] + cmb[t]) + diru_t);
+      double cpb_t = cpb[t], cmb_t = cmb[t], dir_t = dir[t], diru_t = diru[t];
+      if constexpr (PARK) {
+        cpb_t = mine[3 * t];
+        if constexpr (solar) { dir_t = mine[3 * t + 1]; diru_t = mine[3 * t + 2]; }
+        else cmb_t = mine[3 * t + 1];
+      }
+      mine[3 * t] = wcol * (y1 * e.e1 + y2 * e.e2 + cpb_t);
+      mine[3 * t + 1] = wcol * ((y1 * e.e3 + y2 * e.e4 + cmb_t) + dir_t);
+      mine[3 * t + 2] = wcol * (inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + cpb_t + cmb_t) + diru_t);
       if (i == 0) {
-        const double top = (y1 * e.e3 - y2 * e.e4) + cp0[t];
+        const double top = (y1 * e.e3 - y2 * e.e4) + cp0_top;
         double *lv0 = lds + (size_t)wc * nl * 3;
         lv0[0] = wcol * top;
         lv0[1] = wcol * lvl0_dn;
