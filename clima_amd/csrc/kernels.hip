@@ -259,13 +259,14 @@ __device__ const double EXP2_TAB[EXP2_N] = {
     1.9360617934922943, 1.9413109895286405, 1.9465744175792332, 1.9518521162309783,
     1.9571441241754002, 1.9624504802089273, 1.9677712232331759, 1.9731063922552343,
     1.978456026387951, 1.9838201648502194, 1.9891988469672663, 1.9945921121709402};
-__device__ __forceinline__ double exp_tab(double x, const double *s_tab) {
+template <int BASE10>
+__device__ __forceinline__ double exp_tab_any(double x, const double *s_tab) {
   double f, nf, r;
   {
     // (contracted into fma(x, c, -nf), r would be the rounding residual of the product when |f| >= 2^52:
     // huge, and the result inf instead of 0)
 #pragma clang fp contract(off)
-    f = x * 369.3299304675746;    // 256/ln2
+    f = x * (BASE10 ? 850.4135922911647 : 369.3299304675746);    // 256 log2(10) : 256/ln2
     nf = __builtin_rint(f);
     r = f - nf;
   }
@@ -278,6 +279,10 @@ __device__ __forceinline__ double exp_tab(double x, const double *s_tab) {
   p = __builtin_fma(p, r, 1.0);
   return __builtin_ldexp(t * p, n >> 8);
 }
+__device__ __forceinline__ double exp_tab(double x, const double *s_tab) { return exp_tab_any<0>(x, s_tab); }
+// 10^y the same way (ten2power, src/clima_eqns.f90:75-80, for the opacity tile's table interpolations:
+// 14 instructions where ten2power() below takes 24); relative error <= 1.5 ulp + |y| * 2.6e-16
+__device__ __forceinline__ double ten2power_tab(double y, const double *s_tab) { return exp_tab_any<1>(y, s_tab); }
 // 1/x with one Newton step on v_rcp_f64: relative error <= 2e-15 (tests/devtools/gpu_rcp_accuracy.py),
 // for factors that enter sums of weighted source terms
 __device__ __forceinline__ double rcp_n1(double x) {
@@ -735,6 +740,8 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   if (tid < NG + 4) s_E[tid] = p.wbin_e_pad[tid];
   // wave-uniform tables read where they are used: the g-point edges E_0..E_8, then the g-point weights
   __shared__ double s_Ew[2 * NG + 1];
+  __shared__ double s_e2[EXP2_N];   // exp table of ten2power_tab
+  for (int i = tid; i < EXP2_N; i += OP_THREADS) s_e2[i] = EXP2_TAB[i];
   if (tid < NG + 1) s_Ew[tid] = p.wbin_e[tid];
   else if (tid < 2 * NG + 1) s_Ew[tid] = p.wbin[tid - (NG + 1)];
   // 1/(E_{k+1}-E_k), read at the end of every rebin: wave-uniform values that the compiler kept in (and
@@ -798,7 +805,7 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
         if (e0 + u < p.nabs) {
           const AbsEntry &x = p.abs[e0 + u];
           double sgm = v0[u];
-          if (x.nT) sgm = ten2power((1.0 - qq[u]) * v0[u] + qq[u] * v1[u]);  // lerp1 + ten2power (:910-912)
+          if (x.nT) sgm = ten2power_tab((1.0 - qq[u]) * v0[u] + qq[u] * v1[u], s_e2);  // lerp1 + ten2power (:910-912)
           taua = taua + sgm * ww[u];
         }
       }
@@ -859,7 +866,7 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
       // linear_interp_2d%evaluate, linear_interpolation_module.F90:319-327
       const double fx1 = p1 * f11[g] + q1 * f21[g];
       const double fx2 = p1 * f12[g] + q1 * f22[g];
-      kc[g] = ten2power(p2 * fx1 + q2 * fx2) * col;  // :818 / :828
+      kc[g] = ten2power_tab(p2 * fx1 + q2 * fx2, s_e2) * col;  // :818 / :828
     }
   };
   double tk[NG];  // tau_k of the running mixture
@@ -3413,15 +3420,15 @@ void launch_test_rcp(const double *x, double *y, int n, hipStream_t s) {
 void launch_test_exp(const double *x, double *y, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_test_exp, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
 }
-__global__ __launch_bounds__(256) void k_test_exp_tab(const double *x, double *y, int n) {
+__global__ __launch_bounds__(256) void k_test_exp_tab(const double *x, double *y, int n, int base10) {
   __shared__ double s_e2[EXP2_N];
   for (int i = threadIdx.x; i < EXP2_N; i += blockDim.x) s_e2[i] = EXP2_TAB[i];
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) y[i] = exp_tab(x[i], s_e2);
+  if (i < n) y[i] = base10 ? ten2power_tab(x[i], s_e2) : exp_tab(x[i], s_e2);
 }
-void launch_test_exp_tab(const double *x, double *y, int n, hipStream_t s) {
-  hipLaunchKernelGGL(k_test_exp_tab, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
+void launch_test_exp_tab(const double *x, double *y, int n, int base10, hipStream_t s) {
+  hipLaunchKernelGGL(k_test_exp_tab, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n, base10);
 }
 
 __global__ void k_copy(double *dst, const double *src, size_t n) {

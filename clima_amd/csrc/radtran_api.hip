@@ -1774,14 +1774,15 @@ void clima_test_device_exp(const int *n, const double *x, double *y, char *err) 
   CATCH(err)
 }
 
-// the table exp of the zenith-angle loop (arguments <= 0)
-void clima_test_device_exp_table(const int *n, const double *x, double *y, char *err) {
+// the table exp of the zenith-angle loop (base10 = 0: e^x, arguments <= 0) and of the opacity tile's
+// table interpolations (base10 = 1: 10^x)
+void clima_test_device_exp_table(const int *n, const int *base10, const double *x, double *y, char *err) {
   clear_err(err);
   TRY
   DevBuf<double> dx, dy;
   dx.alloc(*n); dy.alloc(*n);
   HIPCHK(hipMemcpy(dx.p, x, sizeof(double) * *n, hipMemcpyHostToDevice));
-  launch_test_exp_tab(dx.p, dy.p, *n, nullptr);
+  launch_test_exp_tab(dx.p, dy.p, *n, *base10, nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(y, dy.p, sizeof(double) * *n, hipMemcpyDeviceToHost));
   CATCH(err)

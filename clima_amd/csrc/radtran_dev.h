@@ -264,6 +264,6 @@ void launch_copy(double *dst, const double *src, size_t n, hipStream_t s);  // s
 void launch_test_rcp(const double *x, double *y, int n, hipStream_t s);
 void launch_test_wscan(const double *a, const double *b, double *out, int nwaves, hipStream_t s);
 void launch_test_exp(const double *x, double *y, int n, hipStream_t s);
-void launch_test_exp_tab(const double *x, double *y, int n, hipStream_t s);
+void launch_test_exp_tab(const double *x, double *y, int n, int base10, hipStream_t s);
 
 }  // namespace clima

@@ -64,7 +64,7 @@ SIGNATURES = {
     "radtran_algorithmic_nodes": [_vp, _dp, _dp, _dp, _dp, _err],
     "radtran_opr_get": [_vp, _dp, _dp, _dp, _dp, _err],
     "clima_test_device_exp": [_ip, _dp, _dp, _err],
-    "clima_test_device_exp_table": [_ip, _dp, _dp, _err],
+    "clima_test_device_exp_table": [_ip, _ip, _dp, _dp, _err],
     "clima_test_device_rcp": [_ip, _dp, _dp, _err],
     "clima_test_wave_scan": [_ip, _dp, _dp, _dp, _err],
     "clima_test_two_stream": [_ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],

@@ -209,7 +209,7 @@ void radtran_algorithmic_nodes(void *ptr, double *n_pt, double *n_pt_full, doubl
 
 /* test hook: y[i] = the kernels' device exp(x[i]) (used where the reference calls exp) */
 void clima_test_device_exp(const int *n, const double *x, double *y, char *err);
-void clima_test_device_exp_table(const int *n, const double *x, double *y, char *err);
+void clima_test_device_exp_table(const int *n, const int *base10, const double *x, double *y, char *err);
 /* test hook: the device reciprocal with 0, 1 and 2 Newton steps, and the device sqrt of |x|
  * (y: 4 arrays of n) */
 void clima_test_device_rcp(const int *n, const double *x, double *y, char *err);

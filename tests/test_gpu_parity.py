@@ -124,7 +124,7 @@ def test_device_exp_table(hip_lib):
     y = np.empty_like(x)
     err = C.create_string_buffer(1025)
     dp = C.POINTER(C.c_double)
-    hip_lib.clima_test_device_exp_table(C.byref(C.c_int(len(x))), x.ctypes.data_as(dp), y.ctypes.data_as(dp), err)
+    hip_lib.clima_test_device_exp_table(C.byref(C.c_int(len(x))), C.byref(C.c_int(0)), x.ctypes.data_as(dp), y.ctypes.data_as(dp), err)
     assert err.value == b""
     with np.errstate(under="ignore"):
         ref = np.exp(x)
@@ -134,6 +134,32 @@ def test_device_exp_table(hip_lib):
     assert np.all(y[ref == 0.0] == 0.0)
     assert np.all(np.abs(y[~normal] - ref[~normal]) <= 1e-300)
     assert y[-11] == 1.0 and y[-10] == 1.0        # exp(0), exp(-0)
+
+
+def test_device_ten2power_table(hip_lib):
+    """10^y of the opacity tile's table interpolations (log10 k, log10 sigma: -60 ... +5), table form:
+    within 1.5 ulp + |y| ln(10) 2^-53 relative of the correctly rounded value."""
+    import ctypes as C
+    from decimal import Decimal, getcontext
+    rng = np.random.default_rng(3)
+    y = np.concatenate([rng.uniform(-60, 5, 200000), rng.uniform(-300, -60, 2000), rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, 1.0, -1.0, 2.0, -330.0, -400.0]])
+    out = np.empty_like(y)
+    err = C.create_string_buffer(1025)
+    dp = C.POINTER(C.c_double)
+    hip_lib.clima_test_device_exp_table(C.byref(C.c_int(len(y))), C.byref(C.c_int(1)), y.ctypes.data_as(dp), out.ctypes.data_as(dp), err)
+    assert err.value == b""
+    # reference: 10^y in extended precision for a sample, float64 power for the rest (itself good to < 1 ulp)
+    with np.errstate(under="ignore"):
+        ref = np.power(10.0, y)
+    getcontext().prec = 40
+    for i in rng.integers(0, 200000, 300):
+        ref[i] = float(Decimal(10) ** Decimal(float(y[i])))
+    normal = ref > 1e-300
+    rel = np.abs(out[normal] - ref[normal]) / ref[normal]
+    bound = (2.5 + np.abs(y[normal]) * np.log(10.0)) * 2.0 ** -52      # (+1 ulp for the float64 reference)
+    assert np.all(rel <= bound), (rel / bound).max()
+    assert np.all(out[ref == 0.0] == 0.0)
+    assert out[-7] == 1.0 and out[-6] == 1.0 and abs(out[-5] - 10.0) <= 2e-15 * 10 and abs(out[-3] - 100.0) <= 1e-13
 
 
 def test_device_rcp_and_sqrt(hip_lib):

@@ -4,7 +4,7 @@ assembly.  A wave of these kernels stalls for an L2 round trip on every scratch 
 only in where the register allocator spilled differ by several us per call: the hot
 kernels should show no scratch instruction at all between their first and last lines.
 
-  python tools/scratch_report.py [-D...] [pattern]     (cross-compiles: no GPU needed, ~1 min)
+  python tools/scratch_report.py [-D...] [regex on the mangled name]     (cross-compiles: no GPU needed, ~1 min)
 """
 import os, re, subprocess, sys, tempfile
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -29,9 +29,11 @@ with tempfile.TemporaryDirectory() as d:
         elif "scratch_store" in line:
             st += 1; where.append(n)
         elif line.startswith(".Lfunc_end"):
-            if pat in name:
+            if re.search(pat, name):
                 rows.append((name, n, ld, st, where))
             name = None
+if not rows:
+    sys.exit("no kernel matches %r" % pat)
 dem = subprocess.run(["c++filt"] + [r[0] for r in rows], capture_output=True, text=True).stdout.split("\n")
 for (name, n, ld, st, where), dn in zip(rows, dem):
     short = dn.split("(")[0].replace("void clima::", "")
