@@ -9,7 +9,12 @@ LIB = os.path.join(CSRC, "libclima_radtran_hip.so")
 SOURCES = ["kernels.hip", "radtran_api.hip"]
 DEPS = SOURCES + ["radtran_dev.h", "sort_network_64.inc", os.path.join("..", "..", "include", "clima_radtran_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+# The kernels take their parameter blocks by value; hipcc reads them straight from the kernel-argument
+# segment (scalar loads) only while a block has at most `instcombine-max-copied-from-constant-users` uses
+# (default 300) -- beyond that it copies the whole block to scratch at kernel entry and every access becomes
+# a scratch load.  The unrolled opacity tile has more uses than that.
+LLVM_FLAGS = ["-mllvm", "-instcombine-max-copied-from-constant-users=100000"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"] + LLVM_FLAGS
 
 
 def is_stale():

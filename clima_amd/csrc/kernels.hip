@@ -3151,10 +3151,14 @@ static FusedKern fused_kernel_paired(int slots) {
 static int half_slots(const OpacityParams &op, const TwoStreamParams &ts) {
   static const bool off = [] { const char *e = getenv("CLIMA_HIP_NO_HALF"); return e && e[0] == '1'; }();
   if (off || ts.ng != 8 || op.rebin_mode != 0 || op.cust.on) return 0;
-  const int s = (ts.nz + 31) / 32;
-  return s == 7 ? s : 0;
+  const int s = (ts.nz + 31) / 32;   // 65-224 layers: 3-7 slots (225-256 would take 8: the whole-wave form's 4 fill the lanes as well)
+  return (s >= 3 && s <= 7) ? s : 0;
 }
-static FusedKern fused_kernel_half(int slots) { (void)slots; return (FusedKern)k_fused<0, false, 7, false, true>; }
+static FusedKern fused_kernel_half(int slots) {
+  static const FusedKern k[5] = {k_fused<0, false, 3, false, true>, k_fused<0, false, 4, false, true>, k_fused<0, false, 5, false, true>,
+                                 k_fused<0, false, 6, false, true>, k_fused<0, false, 7, false, true>};
+  return k[slots - 3];
+}
 static FusedKern fused_kernel(const OpacityParams &op, int slots) {
   static const FusedKern k04[2][3] = {{k_fused<0, false, 0>, k_fused<1, false, 0>, k_fused<2, false, 0>},
                                       {k_fused<0, true, 0>, k_fused<1, true, 0>, k_fused<2, true, 0>}};
@@ -3192,7 +3196,7 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
 
 bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s, bool half) {
   if (ts.ng != 8 || slots < 2 || slots > 8 || (ts.nz + 63) / 64 > slots || ts.nzen > MAX_ZEN) return false;
-  if (half && (slots != 7 || (ts.nz + 31) / 32 > slots)) return false;
+  if (half && (slots < 3 || slots > 7 || (ts.nz + 31) / 32 > slots)) return false;
   OpacityParams op;
   memset(&op, 0, sizeof(op));
   op.nz = ts.nz;

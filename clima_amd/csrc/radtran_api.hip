@@ -1820,7 +1820,8 @@ void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, d
 // channels, `ng` g-points carrying the same tau/w0 with weights wbin (sum 1), one zenith angle u0 of
 // weight 1, unit stellar flux and unit factors, so the kernels' weighted sums reproduce the solver's
 // own outputs.  form: 0 wave-per-column kernel (k_twostream_w<slots>), 1 workgroup-per-bin kernel
-// (k_twostream), 2 the two-stream part of the fused grid (k_fused, slots 2..4, ng = 8),
+// (k_twostream), 2 the two-stream part of the fused grid (k_fused, slots 2..4, ng = 8), 4 the same in the
+// half-wave form (two g-point columns per wave, slots = ceil(nz/32) = 3..7),
 // 3 batched shared-opacity IR kernel (k_twostream_ir_batch<slots>, IR outputs only).
 // slots = layer slots per lane (>= ceil(nz/64)).  Outputs are TOA-first like the solver's.
 void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, const int *slots, const double *tau,

@@ -14,7 +14,7 @@ pat = ([a for a in sys.argv[1:] if not a.startswith("-")] + ["k_"])[0]
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only",
-                           "-w", src, "-o", out] + flags)
+                           "-w", "-mllvm", "-instcombine-max-copied-from-constant-users=100000", src, "-o", out] + flags)
     name, n, rows = None, 0, []
     for line in open(out):
         m = re.match(r"^(_ZN5clima\w+):", line)
