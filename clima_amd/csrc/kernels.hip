@@ -546,6 +546,7 @@ __device__ __forceinline__ void rebin_window(const double (&key)[64], const bool
       for (int u = 0; u < RB; u++)
         wn[u] = key_weight(key[pb + RB + u], s_wxy);
     }
+    const double Cb = C, ICb = IC;   // the running sums at the batch's first element (for the wide-only pass below)
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const int j = pb + u;
@@ -555,21 +556,26 @@ __device__ __forceinline__ void rebin_window(const double (&key)[64], const bool
         if (j >= rb_lo<true>(k) && j <= rb_hi<true>(k))
           Ie[k] = dmax(Ie[k], __builtin_fma(v, E[k] - C, IC));
       }
-      bool wide_only = false;
-#pragma unroll
-      for (int k = 1; k < 8; k++)
-        wide_only = wide_only || (j >= rb_lo<false>(k) && j <= rb_hi<false>(k) && !(j >= rb_lo<true>(k) && j <= rb_hi<true>(k)));
-      if (wide_only) {
-        if (!xys) {
-#pragma unroll
-          for (int k = 1; k < 8; k++) {
-            if (j >= rb_lo<false>(k) && j <= rb_hi<false>(k) && !(j >= rb_lo<true>(k) && j <= rb_hi<true>(k)))
-              Ie[k] = dmax(Ie[k], __builtin_fma(v, E[k] - C, IC));
-          }
-        }
-      }
       IC = __builtin_fma(v, wv[u], IC);  // weights_to_bins (clima_eqns.f90:43-54) and the integral, in sorted order
       C = C + wv[u];
+    }
+    // the pairs only the wide table holds, for the batch's eight elements behind ONE wave-uniform test (a
+    // test per element cost ~90 scalar and branch instructions per rebin): the running sums are formed
+    // again from the batch's start, same operations in the same order
+    if (!xys) {
+      double c2 = Cb, ic2 = ICb;
+#pragma unroll
+      for (int u = 0; u < RB; u++) {
+        const int j = pb + u;
+        const double v = key[j];
+#pragma unroll
+        for (int k = 1; k < 8; k++) {
+          if (j >= rb_lo<false>(k) && j <= rb_hi<false>(k) && !(j >= rb_lo<true>(k) && j <= rb_hi<true>(k)))
+            Ie[k] = dmax(Ie[k], __builtin_fma(v, E[k] - c2, ic2));
+        }
+        ic2 = __builtin_fma(v, wv[u], ic2);
+        c2 = c2 + wv[u];
+      }
     }
   }
   Ie[8] = IC;  // the last edge is the total weight

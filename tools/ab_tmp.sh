@@ -1,6 +1,4 @@
 set -e
-python -m pytest tests -x -q -m gpu > gpurun_out/r02m_tests.log 2>&1 || { tail -30 gpurun_out/r02m_tests.log; exit 1; }
-tail -2 gpurun_out/r02m_tests.log
-python tools/gpu_nz_sweep.py
-echo NO_HALF
-CLIMA_HIP_NO_HALF=1 python tools/gpu_nz_sweep.py
+python -m pytest tests/test_gpu_golden.py tests/test_gpu_parity.py tests/test_gpu_full_size.py -x -q -m gpu > gpurun_out/r02j_parity.log 2>&1 || { tail -30 gpurun_out/r02j_parity.log; exit 1; }
+tail -3 gpurun_out/r02j_parity.log
+bash tools/gpu_ab.sh "$@"
