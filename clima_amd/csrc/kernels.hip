@@ -259,14 +259,16 @@ __device__ const double EXP2_TAB[EXP2_N] = {
     1.9360617934922943, 1.9413109895286405, 1.9465744175792332, 1.9518521162309783,
     1.9571441241754002, 1.9624504802089273, 1.9677712232331759, 1.9731063922552343,
     1.978456026387951, 1.9838201648502194, 1.9891988469672663, 1.9945921121709402};
-template <int BASE10>
-__device__ __forceinline__ double exp_tab_any(double x, const double *s_tab) {
+constexpr double EXP2_PER_E = 369.3299304675746, EXP2_PER_10 = 850.4135922911647;   // 256/ln2, 256 log2(10)
+// 2^(x k / 256): k = EXP2_PER_E for e^x, EXP2_PER_10 for 10^x -- or that times a factor of the argument
+// the caller has at hand (the zenith-angle loop passes tau' and -EXP2_PER_E/u0: one product instead of two)
+__device__ __forceinline__ double exp_tab_any(double x, double k, const double *s_tab) {
   double f, nf, r;
   {
-    // (contracted into fma(x, c, -nf), r would be the rounding residual of the product when |f| >= 2^52:
+    // (contracted into fma(x, k, -nf), r would be the rounding residual of the product when |f| >= 2^52:
     // huge, and the result inf instead of 0)
 #pragma clang fp contract(off)
-    f = x * (BASE10 ? 850.4135922911647 : 369.3299304675746);    // 256 log2(10) : 256/ln2
+    f = x * k;
     nf = __builtin_rint(f);
     r = f - nf;
   }
@@ -279,10 +281,10 @@ __device__ __forceinline__ double exp_tab_any(double x, const double *s_tab) {
   p = __builtin_fma(p, r, 1.0);
   return __builtin_ldexp(t * p, n >> 8);
 }
-__device__ __forceinline__ double exp_tab(double x, const double *s_tab) { return exp_tab_any<0>(x, s_tab); }
+__device__ __forceinline__ double exp_tab(double x, const double *s_tab) { return exp_tab_any(x, EXP2_PER_E, s_tab); }
 // 10^y the same way (ten2power, src/clima_eqns.f90:75-80, for the opacity tile's table interpolations:
 // 14 instructions where ten2power() below takes 24); relative error <= 1.5 ulp + |y| * 2.6e-16
-__device__ __forceinline__ double ten2power_tab(double y, const double *s_tab) { return exp_tab_any<1>(y, s_tab); }
+__device__ __forceinline__ double ten2power_tab(double y, const double *s_tab) { return exp_tab_any(y, EXP2_PER_10, s_tab); }
 // 1/x with one Newton step on v_rcp_f64: relative error <= 2e-15 (tests/devtools/gpu_rcp_accuracy.py),
 // for factors that enter sums of weighted source terms
 __device__ __forceinline__ double rcp_n1(double x) {
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
       if (kind == ABS_CIA) w = c.dens[a * nz + j] * c.dens[b * nz + j] * c.dz[j];
       else if (kind == ABS_COLUMN) w = c.dens[a * nz + j] * c.dz[j];
       else if (kind == ABS_H2O_SELF) w = c.dens[a * nz + j] * (c.dens[a * nz + j] * c.dz[j]);
+      else if (kind == ABS_ZERO) w = 0.0;
       else {
         double fc = 0.0;  // foreign column (:610-619)
         for (int i = 0; i < p.nsp; i++)
@@ -561,7 +564,8 @@ __device__ __forceinline__ void rebin_window(const double (&key)[64], const bool
     }
     // the pairs only the wide table holds, for the batch's eight elements behind ONE wave-uniform test (a
     // test per element cost ~90 scalar and branch instructions per rebin): the running sums are formed
-    // again from the batch's start, same operations in the same order
+    // again from the batch's start, same operations in the same order.  (One such pass over all 64
+    // elements after the loop, a single test per rebin, made hipcc spill 110 registers: 165 us per call.)
     if (!xys) {
       double c2 = Cb, ic2 = ICb;
 #pragma unroll
@@ -786,34 +790,34 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
     // ---- continuum absorption: CIA, photolysis/absorption, H2O continuum (:665-677, :696-723).
     // Entries are processed eight at a time with every load of the batch issued before the
     // first use, so the dependent index -> table round trips overlap instead of queueing.
+    // The host pads the list to a multiple of ABS_BATCH with terms of weight 0, so a batch needs no
+    // per-term test (a branch costs a wave about four instruction slots).
     double taua = 0.0;
-    constexpr int AB = 8;
+    constexpr int AB = ABS_BATCH;
     for (int e0 = 0; e0 < p.nabs; e0 += AB) {
       int ixx[AB];
       double qq[AB], ww[AB];
   #pragma unroll
       for (int u = 0; u < AB; u++) {
-        const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
+        const AbsEntry &x = p.abs[e0 + u];
         ixx[u] = c.ix[2 * opf + x.slot * nz + jl];
         qq[u] = c.q[opf + x.slot * nz + jl];
-        ww[u] = c.absw[opf + min(e0 + u, p.nabs - 1) * nz + jl];
+        ww[u] = c.absw[opf + (e0 + u) * nz + jl];
       }
       double v0[AB], v1[AB];
   #pragma unroll
       for (int u = 0; u < AB; u++) {
-        const AbsEntry &x = p.abs[min(e0 + u, p.nabs - 1)];
+        const AbsEntry &x = p.abs[e0 + u];
         const double *base = x.data + (x.nT ? (size_t)l * x.nT + ixx[u] : (size_t)l);
         v0[u] = base[0];
         v1[u] = base[x.nT ? 1 : 0];
       }
   #pragma unroll
       for (int u = 0; u < AB; u++) {
-        if (e0 + u < p.nabs) {
-          const AbsEntry &x = p.abs[e0 + u];
-          double sgm = v0[u];
-          if (x.nT) sgm = ten2power_tab((1.0 - qq[u]) * v0[u] + qq[u] * v1[u], s_e2);  // lerp1 + ten2power (:910-912)
-          taua = taua + sgm * ww[u];
-        }
+        const AbsEntry &x = p.abs[e0 + u];
+        double sgm = v0[u];
+        if (x.nT) sgm = ten2power_tab((1.0 - qq[u]) * v0[u] + qq[u] * v1[u], s_e2);  // lerp1 + ten2power (:910-912)
+        taua = taua + sgm * ww[u];
       }
     }
     // ---- custom opacity (:540-572, :726-730); tiny everywhere when unset (:558-562)
@@ -2330,10 +2334,11 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       wsum = wsum + wz;
       dir0 = dir0 + wz * u0;
       const double iu2 = iu * iu, wzu = wz * u0;
+      const double kz = -iu * EXP2_PER_E;   // exp(-tau'/u0) = 2^(tau' kz / 256)
 #ifdef CLIMA_ZEN_EXP_POLY
       double et = fexp(-tauc0 * iu);
 #else
-      double et = exp_tab(-tauc0 * iu, s_e2);
+      double et = exp_tab_any(tauc0, kz, s_e2);
 #endif
       double ex = 0.0, R = 0.0, sR = 0.0;  // attenuation and source factors of the current layer (pair)
 #pragma unroll
@@ -2342,7 +2347,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 #ifdef CLIMA_ZEN_EXP_POLY
           ex = fexp(-taup[t] * iu);  // :79
 #else
-          ex = exp_tab(-taup[t] * iu, s_e2);  // :79
+          ex = exp_tab_any(taup[t], kz, s_e2);  // :79
 #endif
           R = wz * rcp_n1(__builtin_fma(lam[t], lam[t], -iu2));   // w_z / denom (:80)
           sR = __builtin_fma(-zB[t], u0, iu) * R;                   // s w_z / denom

@@ -149,7 +149,8 @@ struct Radtran {
   bool all_pairs_exact = false;  // ... and every layer is half of an exact pair (the doubled radiative grid)
   DevBuf<double> d_prep;  // one block: [log10P | cols | foreign_col | absw | q | ix (ints)]
   size_t prep_count = 0;
-  std::vector<AbsEntry> abs_entries;  // continuum terms in the reference's summation order
+  std::vector<AbsEntry> abs_entries;  // continuum terms in the reference's summation order (+ zero-weight padding)
+  DevBuf<double> d_zero_xs;
   DevBuf<int> d_err;
 #ifdef CLIMA_STAMPS
   DevBuf<long long> d_stamps;
@@ -1208,7 +1209,13 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
     r->abs_entries.push_back(AbsEntry{r->d_cont_H2O.p, r->cont_nT, slot, ABS_H2O_SELF, r->LH2O, 0});
     r->abs_entries.push_back(AbsEntry{r->d_cont_foreign.p, r->cont_nT, slot, ABS_H2O_FOREIGN, r->LH2O, 0});
   }
-  if ((int)r->abs_entries.size() > MAX_ABS) throw HipFail{"too many continuum terms for this build"};
+  if ((int)r->abs_entries.size() > MAX_ABS - (ABS_BATCH - 2)) throw HipFail{"too many continuum terms for this build"};
+  // the opacity tile takes the terms in batches of ABS_BATCH without per-term tests: the list is padded with
+  // terms of weight 0 on a table of zeros (they add +0.0 at the end of the sum)
+  if (r->abs_entries.size() % ABS_BATCH) {
+    r->d_zero_xs.upload(std::vector<double>((size_t)r->nw + 1, 0.0));
+    while (r->abs_entries.size() % ABS_BATCH) r->abs_entries.push_back(AbsEntry{r->d_zero_xs.p, 0, 0, ABS_ZERO, 0, 0});
+  }
   r->part_slot.clear();
   for (auto *p : r->part) {
     p->d_radii.upload(p->radii); p->d_w0.upload(p->w0); p->d_qext.upload(p->qext); p->d_gt.upload(p->gt);

@@ -59,8 +59,9 @@ struct XsDev {
 // summation order: CIA pairs, photolysis/absorption, H2O self and foreign continuum.
 // tau = sigma(bin, T_layer) * weight(layer); the weight is bin-independent and is formed
 // once per call by the prep kernel.
-constexpr int MAX_ABS = 2 * 16 + 2;
-enum { ABS_CIA = 0, ABS_COLUMN = 1, ABS_H2O_SELF = 2, ABS_H2O_FOREIGN = 3 };
+constexpr int ABS_BATCH = 8;          // the opacity tile takes continuum terms in batches of this many; the host pads the list
+constexpr int MAX_ABS = 2 * 16 + 2 + 6;  // (2 MAX_XS + 2 real terms, rounded up to a multiple of ABS_BATCH)
+enum { ABS_CIA = 0, ABS_COLUMN = 1, ABS_H2O_SELF = 2, ABS_H2O_FOREIGN = 3, ABS_ZERO = 4 };  // ABS_ZERO: padding, weight 0
 struct AbsEntry {
   const double *data;  // nT == 0: xs[nw]; else log10 xs [nw][nT]
   int nT;              // 0 for constant (0-D) cross sections
