@@ -2162,9 +2162,6 @@ constexpr int TSW_COLS = 4;  // waves (g-point columns) per block
 // wave's run time follows its instruction count (see fast_exp); an earlier form that branched on
 // every layer's presence spent a third of its instructions on that bookkeeping.
 // ------------------------------------------------------------------------------------
-// dynamic LDS of a block of twostream_p_body<L, ...>: three level values per (thread, slot), the column
-// tops (3 x at most 8 columns), the bin's Planck table
-static size_t ts_stage_lds(int nz, int L) { return sizeof(double) * ((size_t)64 * TSW_COLS * 3 * L + 24 + (size_t)nz + 1); }
 // element offsets of a batch column (all 0 for a single call)
 struct TsOfs {
   size_t opr, col, res;
@@ -2259,16 +2256,14 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 
   double G[L], X[L], cp0[L], cm0[L], cpb[L], cmb[L], dir[L], diru[L];
   double Rsfc, Ssfc = 0.0, lvl0_dn = 0.0, lvl0_am = 0.0;
-  // The block's level values in LDS, SLOT-major: thread x's slot t owns lds[(x L + t) 3 + k], k = 0
-  // up-flux, 1 down-flux, 2 mean intensity of the level under that slot's layer -- every slot has entries
-  // of its own, zero-thickness ones included, so nothing that touches them needs a test of the slot (a
-  // branch costs a wave about four instruction slots, and there were five per slot), and a lane addresses
-  // all of them at constant offsets from ONE register.  The levels' owners are found again by the
-  // g-point sum at the end; the column tops have 3 NCOL entries behind the slots, the Planck table follows.
-  double *const mine = lds + (size_t)threadIdx.x * (3 * L);
-  double *const tops = lds + (size_t)blockDim.x * (3 * L);
+  // this column's rows of the block's level values (each lane writes the levels under its own layers)
+  // (level n of column w: lds[(w nl + n) 3 + k], k = 0 up-flux, 1 down-flux, 2 mean intensity.  `mine`
+  // is the entry of the level under the lane's slot 0 -- slot t's is mine[3 t + k], at constant offsets
+  // from ONE per-lane address; it is only dereferenced for t >= pad, where it lies in the lane's range)
+  double *const mine = lds + ((size_t)wc * nl + (a - pad + 1)) * 3;
   // PARK (5 and more slots per lane): what the zenith-angle loop does not touch waits in LDS instead of
-  // in registers -- Gamma, A and w0/2 of a slot in its three entries -- and the direct beam
+  // in registers -- Gamma, A and w0/2 of a layer in the lane's own three entries of its level (a
+  // zero-thickness slot has no entry and needs none: its Gamma and w0/2 are 0) -- and the direct beam
   // goes to the down-flux / mean-intensity entries as soon as it is summed.  With everything in registers the 7-slot
   // form spilled 25-120 of them to scratch, and every reload stalls the wave for an L2 round trip:
   // variants with FEWER instructions but more spills ran slower.
@@ -2326,7 +2321,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     if constexpr (PARK) {
 #pragma unroll
       for (int t = 0; t < L; t++)
-      { mine[3 * t] = G[t]; mine[3 * t + 1] = zA[t]; mine[3 * t + 2] = zH[t]; }
+        if (t >= pad) { mine[3 * t] = G[t]; mine[3 * t + 1] = zA[t]; mine[3 * t + 2] = zH[t]; }
     }
     __syncthreads();  // s_e2
     TSTAMP(1);
@@ -2385,13 +2380,18 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     for (int t = 0; t < L; t++) {
       double zAt = zA[t], zHt = zH[t];
       if constexpr (PARK) {
-        G[t] = mine[3 * t]; zAt = mine[3 * t + 1]; zHt = mine[3 * t + 2];
-        mine[3 * t + 1] = dir[t]; mine[3 * t + 2] = diru[t];
+        G[t] = 0.0; zAt = 0.0; zHt = 0.0;   // a zero-thickness slot: w0' = 0 -> gamma2 = 0, Gamma = 0 (A: any finite value)
+        if (t >= pad) {
+          G[t] = mine[3 * t]; zAt = mine[3 * t + 1]; zHt = mine[3 * t + 2];
+          mine[3 * t + 1] = dir[t]; mine[3 * t + 2] = diru[t];
+        }
       }
       const double a0 = zAt * cp0[t], s0 = cm0[t], ab = zAt * cpb[t], sb = cmb[t];
       cp0[t] = zHt * (a0 - s0); cm0[t] = zHt * (a0 + s0);
       cpb[t] = zHt * (ab - sb); cmb[t] = zHt * (ab + sb);
-      if constexpr (PARK) mine[3 * t] = cpb[t];
+      if constexpr (PARK) {
+        if (t >= pad) mine[3 * t] = cpb[t];
+      }
       if (PAIRED && (t & 1)) X[t] = X[t - 1];
       else X[t] = fexp(-lam[t] * taup[t]);  // :56
     }
@@ -2405,7 +2405,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     const double *Tsfc = p.T_surface + co.col + (size_t)bz * p.b_Ts;
     // Planck source at the levels (radiate.f90:65-69): the same for the block's g-point columns, so
     // each of the nz+1 values is computed once per block instead of L+1 times per lane of every wave
-    double *sB = tops + 3 * NCOL;
+    double *sB = lds + (size_t)3 * NCOL * nl;
     for (int n = threadIdx.x; n < nl; n += blockDim.x)  // TOA-first level
       sB[n] = p.bplanck ? p.bplanck[n] : planck(avg_freq, n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);
     __syncthreads();
@@ -2444,7 +2444,9 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
       cm0[t] = norm * (b0n + b1n * (-r));
       cmb[t] = norm * (b0n + b1n * (tau_in - r));
       dir[t] = diru[t] = 0.0;
-      if constexpr (PARK) { mine[3 * t] = cpb[t]; mine[3 * t + 1] = cmb[t]; }
+      if constexpr (PARK) {
+        if (t >= pad) { mine[3 * t] = cpb[t]; mine[3 * t + 1] = cmb[t]; }
+      }
     }
     {  // surface source (:236-247), used by the surface row only
       const double tau_in = tau_s[L - 1], bpl_top = bpl[L - 1], bpl_bot = bpl[L];
@@ -2462,6 +2464,10 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   //      Row 2t-1 couples slots t-1,t (Fortran even rows, :106-112), row 2t likewise (odd rows,
   //      :97-103); row 0 and row 2L-1 are the flux boundary rows (TOA :93-96 / surface :113-117 at
   //      the column ends).
+  // C+(0) of the lane's first real layer (the column top's source in lane 0: the last lines use it)
+  double cp0_top = cp0[0];
+#pragma unroll
+  for (int t = 1; t < L; t++) cp0_top = (t == pad) ? cp0[t] : cp0_top;
   double rc[2 * L], rd[2 * L], rl[2 * L];
   {
     double cp, dp, lp;
@@ -2548,25 +2554,27 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   // ---- level fluxes (:143-148, :288-293), mean intensity (:135-140), g-point weight
 #pragma unroll
   for (int t = 0; t < L; t++) {
+    const int i = a + t - pad;
     const E4 e = make_e(G[t], X[t]);
     const double y1 = rd[2 * t] + rc[2 * t] * Uin + rl[2 * t] * Din;
     const double y2 = rd[2 * t + 1] + rc[2 * t + 1] * Uin + rl[2 * t + 1] * Din;
-    double cpb_t = cpb[t], cmb_t = cmb[t], dir_t = dir[t], diru_t = diru[t];
-    if constexpr (PARK) {
-      cpb_t = mine[3 * t];
-      if constexpr (solar) { dir_t = mine[3 * t + 1]; diru_t = mine[3 * t + 2]; }
-      else cmb_t = mine[3 * t + 1];
-    }
-    mine[3 * t] = wcol * (y1 * e.e1 + y2 * e.e2 + cpb_t);
-    mine[3 * t + 1] = wcol * ((y1 * e.e3 + y2 * e.e4 + cmb_t) + dir_t);
-    mine[3 * t + 2] = wcol * (inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + cpb_t + cmb_t) + diru_t);
-    if (t == 0 && is_toa) {
-      // the column's top (fup(1), :143) is the top of the first lane's slot 0, whether that slot holds the
-      // first layer or a zero-thickness one in front of it (which hands the flux through)
-      const double top = (y1 * e.e3 - y2 * e.e4) + cp0[0];
-      tops[3 * wc] = wcol * top;
-      tops[3 * wc + 1] = wcol * lvl0_dn;
-      tops[3 * wc + 2] = wcol * (inv_u1 * top + lvl0_am);
+    if (t >= pad) {
+      double cpb_t = cpb[t], cmb_t = cmb[t], dir_t = dir[t], diru_t = diru[t];
+      if constexpr (PARK) {
+        cpb_t = mine[3 * t];
+        if constexpr (solar) { dir_t = mine[3 * t + 1]; diru_t = mine[3 * t + 2]; }
+        else cmb_t = mine[3 * t + 1];
+      }
+      mine[3 * t] = wcol * (y1 * e.e1 + y2 * e.e2 + cpb_t);
+      mine[3 * t + 1] = wcol * ((y1 * e.e3 + y2 * e.e4 + cmb_t) + dir_t);
+      mine[3 * t + 2] = wcol * (inv_u1 * (y1 * (e.e1 + e.e3) + y2 * (e.e2 + e.e4) + cpb_t + cmb_t) + diru_t);
+      if (i == 0) {
+        const double top = (y1 * e.e3 - y2 * e.e4) + cp0_top;
+        double *lv0 = lds + (size_t)wc * nl * 3;
+        lv0[0] = wcol * top;
+        lv0[1] = wcol * lvl0_dn;
+        lv0[2] = wcol * (inv_u1 * top + lvl0_am);
+      }
     }
   }
   TSTAMP(6);
@@ -2587,31 +2595,12 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   // ---- sum over the block's g-points, unit factors (radiate.f90:167-180), reversal (:140-154)
   const bool split = p.accumulate != 0;
   for (int n = threadIdx.x; n < nl; n += blockDim.x) {
-    // where level n's values are: the column tops, or slot ts of lane q -- the lane whose chunk [a, b) holds
-    // layer i = n - 1 (the inverse of the chunk rule at the top of this function)
-    const double *src = tops;
-    int stride = 3;
-    if (n > 0) {
-      const unsigned i = (unsigned)(n - 1);
-      unsigned q, qa, qb;
-      if constexpr (PAIRED) {
-        const unsigned h = (unsigned)nz >> 1;
-        q = ((((i >> 1) + 1u) << 6) - 1u) / h;
-        qa = 2u * ((q * h) >> 6); qb = 2u * (((q + 1u) * h) >> 6);
-      } else {
-        q = (((i + 1u) << WSH) - 1u) / (unsigned)nz;
-        qa = (q * (unsigned)nz) >> WSH; qb = ((q + 1u) * (unsigned)nz) >> WSH;
-      }
-      const unsigned ts = (unsigned)L - (qb - qa) + (i - qa);
-      src = lds + (size_t)(q * L + ts) * 3;
-      stride = W * L * 3;
-    }
     double fu = 0.0, fd = 0.0, am = 0.0;
 #pragma unroll
     for (int w = 0; w < NCOL; w++) {
-      fu = fu + src[(size_t)w * stride];
-      fd = fd + src[(size_t)w * stride + 1];
-      am = am + src[(size_t)w * stride + 2];
+      fu = fu + lds[((size_t)w * nl + n) * 3];
+      fd = fd + lds[((size_t)w * nl + n) * 3 + 1];
+      am = am + lds[((size_t)w * nl + n) * 3 + 2];
     }
     const size_t o = co.res + (size_t)ll * nl + (nz - n);
     if (solar) {
@@ -2643,7 +2632,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 // the second wave
 template <int LMAX>
 __global__ __launch_bounds__(64 * TSW_COLS, LMAX > 4 ? 2 : 1) void k_twostream_w(TwoStreamParams p) {
-  extern __shared__ __align__(16) double lds[];  // ts_stage_lds(): [thread][slot][3] weighted level values, column tops, Planck table
+  extern __shared__ __align__(16) double lds[];  // [TSW_COLS][nz+1][3] weighted level values, then the Planck table
   if ((int)blockIdx.x < p.n_sol) twostream_p_body<LMAX, true, 0, false, false>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
   else twostream_p_body<LMAX, false, 0, false, false>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
 }
@@ -2672,7 +2661,7 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   const int lmax = std::max((p.nz + 63) / 64, p.force_slots);
   if (lmax > 8) return false;
   const int groups = (p.ng + TSW_COLS - 1) / TSW_COLS;
-  const size_t lds = ts_stage_lds(p.nz, lmax);
+  const size_t lds = sizeof(double) * (3 * TSW_COLS + 1) * ((size_t)p.nz + 1);  // level values of the columns + the bin's Planck table
   if (lds_bytes) *lds_bytes = lds;
   if (lds > 64 * 1024) return false;
   const int grid = p.n_sol + p.n_ir;
@@ -3208,7 +3197,7 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
     fp.sol_early = (int)std::min<long>(ts.n_sol, std::max<long>(0, first_round_bins - (long)(ts.sol_start + ts.sol_lo - op.bin_lo)));
   }
   ts.col_base = 0; ts.accumulate = hs ? 0 : 1;   // (a half-wave block holds all 8 g-points of its bin)
-  const size_t lds = ts_stage_lds(ts.nz, fp.slots);
+  const size_t lds = sizeof(double) * (3 * TSW_COLS * (hs ? 2 : 1) + 1) * ((size_t)ts.nz + 1);
   const long items = (long)fp.ncol * (fp.n_op + fp.n_ts);
   const FusedKern k = ps ? fused_kernel_paired(ps) : hs ? fused_kernel_half(hs) : fused_kernel(op, fp.slots);
   if (lds > 48 * 1024 && !ensure_max_lds((const void *)k, 64 * 1024)) return false;  // (the kernel has static LDS too)
@@ -3231,7 +3220,7 @@ bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta
   fp.slots = slots;
   fp.sol_early = ts.n_sol;
   ts.col_base = 0; ts.accumulate = half ? 0 : 1;
-  const size_t lds = ts_stage_lds(ts.nz, slots);
+  const size_t lds = sizeof(double) * (3 * TSW_COLS * (half ? 2 : 1) + 1) * ((size_t)ts.nz + 1);
   const FusedKern k = half ? fused_kernel_half(slots) : fused_kernel(op, slots);
   if (lds > 48 * 1024 && !ensure_max_lds((const void *)k, 64 * 1024)) return false;
   hipLaunchKernelGGL(k, dim3(fp.n_ts), dim3(OP_THREADS), lds, s, op, ts, fp);
