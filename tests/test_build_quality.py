@@ -1,0 +1,55 @@
+"""Build-quality guard (no GPU needed): the hot kernels must compile without scratch (register-spill) traffic
+and without a copy of their parameter blocks to scratch.
+
+A wave of these kernels stalls for an L2 round trip on every scratch reload; builds that differed only in
+where hipcc's register allocator spilled differed by up to 7 us per call, and a parameter block copied to
+scratch at kernel entry (what hipcc does without the flag in clima_amd/build.py) doubles the run time
+("What bounds these kernels").  The check reads the gfx950 assembly hipcc writes for
+clima_amd/csrc/kernels.hip with the build's own flags (tools/scratch_report.py prints the same counts).
+"""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+from clima_amd import build as B
+
+# kernels of the production paths: fused grid, stand-alone opacity tile, group-of-lanes opacity,
+# wave-per-column two-stream, batched IR, prep, integration
+HOT = re.compile(r"k_fused|k_opacity8|k_opacity_coop|k_twostream_w|k_twostream_ir_batch|k_prep|k_integrate_one")
+
+
+@pytest.fixture(scope="module")
+def assembly():
+    if not (os.path.exists(B.HIPCC) or shutil.which(B.HIPCC)):
+        pytest.skip("no hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "kernels.s")
+        flags = [f for f in B.FLAGS if f not in ("-fPIC", "-shared")]
+        subprocess.check_call([B.HIPCC] + flags + ["-S", "--cuda-device-only", "-w", os.path.join(B.CSRC, "kernels.hip"), "-o", out])
+        kernels, name, n_scratch = {}, None, 0
+        for line in open(out):
+            m = re.match(r"^(_ZN5clima\w+):", line)
+            if m:
+                name, n_scratch = m.group(1), 0
+            elif name is not None:
+                if "scratch_" in line:
+                    n_scratch += 1
+                elif line.startswith(".Lfunc_end"):
+                    kernels[name] = n_scratch
+                    name = None
+    return kernels
+
+
+def test_hot_kernels_have_no_scratch_traffic(assembly):
+    hot = {k: v for k, v in assembly.items() if HOT.search(k)}
+    assert len(hot) >= 30, sorted(hot)             # every instantiation of the fused grid and the stand-alone kernels
+    bad = {k: v for k, v in hot.items() if v}
+    assert not bad, "scratch instructions in: %s (python tools/scratch_report.py)" % bad
+
+
+def test_build_flags_keep_parameter_blocks_in_the_kernarg_segment():
+    assert any("instcombine-max-copied-from-constant-users" in f for f in B.FLAGS)
