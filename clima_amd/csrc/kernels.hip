@@ -3165,6 +3165,13 @@ static int half_slots(const OpacityParams &op, const TwoStreamParams &ts) {
   const int s = (ts.nz + 31) / 32;   // 65-224 layers: 3-7 slots (225-256 would take 8: the whole-wave form's 4 fill the lanes as well)
   return (s >= 3 && s <= 7) ? s : 0;
 }
+// slots of the half-wave form when launch_fused() will take it for this call, else 0.  Its blocks hold all 8
+// g-points of a bin and store every output value themselves: the caller need not clear the outputs first.
+int fused_half_form(const OpacityParams &op, const TwoStreamParams &ts, int ncol) {
+  if (!fused_supported(op, ts)) return 0;
+  if (ncol <= 1 && paired_slots(op, ts)) return 0;
+  return half_slots(op, ts);
+}
 static FusedKern fused_kernel_half(int slots) {
   static const FusedKern k[5] = {k_fused<0, false, 3, false, true>, k_fused<0, false, 4, false, true>, k_fused<0, false, 5, false, true>,
                                  k_fused<0, false, 6, false, true>, k_fused<0, false, 7, false, true>};

@@ -586,7 +586,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     ts.paired = (allow_paired && !bc && !r->col_override && compute_opacity && r->all_pairs_exact) ? 1 : 0;
     return ts;
   };
-  bool pre_zeroed = false, fused_done = false;
+  bool pre_zeroed = false, fused_done = false, whole_stores = false;
   if (compute_opacity) {
     PrepParams pp;
     std::memset(&pp, 0, sizeof(pp));
@@ -610,7 +610,19 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
       const char *mode = getenv("CLIMA_HIP_TS_MODE");
       const bool wave_mode = !(mode && std::strcmp(mode, "block") == 0) && (nz + 63) / 64 <= 8;
       pre_zeroed = false;
-      if (wave_mode && twostream_w_groups(r->ng) >= 2) {
+      // (not when the fused grid will run its half-wave form: those blocks store whole values -- 7.7 MB of
+      // zeros per config-2 call that nobody reads)
+      {
+        OpacityParams oq;
+        std::memset(&oq, 0, sizeof(oq));
+        oq.nz = nz; oq.ng = r->ng; oq.nbins = r->op_n; oq.rebin_mode = r->rebin_mode; oq.cust.on = r->cust_on ? 1 : 0;
+        const bool coop = !bc && r->ng == 8 && (long)r->op_n * nsrc <= r->coop_items;
+        if ((bc || (r->fused && allow_fused && !coop)) && wave_mode && twostream_w_groups(r->ng) >= 2) {
+          const TwoStreamParams tq = ts_params();
+          whole_stores = fused_half_form(oq, tq, ncol) != 0;
+        }
+      }
+      if (wave_mode && twostream_w_groups(r->ng) >= 2 && !whole_stores) {
         int n = 0;
         if (r->ir_n > 0) {
           pp.zero_ptr[n] = ir_fup + (size_t)r->ir_lo * nl; pp.zero_count[n++] = nl * r->ir_n;
@@ -650,9 +662,9 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     op.stamps = r->d_stamps.p;
 #endif
     op.tau = o_tau; op.w0 = o_w0; op.g = o_g; op.tau_band = o_tb;
-    if (bc || (r->fused && allow_fused && pre_zeroed && !op.coop)) {
+    if (bc || (r->fused && allow_fused && (pre_zeroed || whole_stores) && !op.coop)) {
       TwoStreamParams tsf = ts_params();
-      if (fused_supported(op, tsf) && pre_zeroed) {
+      if (fused_supported(op, tsf) && (pre_zeroed || whole_stores)) {
         FusedParams fp;
         std::memset(&fp, 0, sizeof(fp));
         fp.ncol = ncol; fp.bs = bs;

@@ -250,6 +250,7 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
 // T + c*b_T, T_surface + c*b_Ts, IR spectra + c*b_out for column c of ncol
 bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s);
 bool fused_supported(const OpacityParams &op, const TwoStreamParams &ts);
+int fused_half_form(const OpacityParams &op, const TwoStreamParams &ts, int ncol);
 int fused_tiles(const OpacityParams &op);   // opacity tiles per column (size of a column's done[] slice)
 bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s);
 // test hook: the two-stream blocks of the fused grid alone (no opacity blocks), on opacities already in HBM
