@@ -746,18 +746,28 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   __shared__ double s_wxy[NG * NG];
   __shared__ double s_E[NG + 4];  // output edges followed by +inf sentinels
   const int tid = threadIdx.x;
-  if (tid < NG * NG) s_wxy[tid] = p.wxy[tid];
-  if (tid < NG + 4) s_E[tid] = p.wbin_e_pad[tid];
   // wave-uniform tables read where they are used: the g-point edges E_0..E_8, then the g-point weights
   __shared__ double s_Ew[2 * NG + 1];
   __shared__ double s_e2[EXP2_N];   // exp table of ten2power_tab
-  for (int i = tid; i < EXP2_N; i += OP_THREADS) s_e2[i] = EXP2_TAB[i];
-  if (tid < NG + 1) s_Ew[tid] = p.wbin_e[tid];
-  else if (tid < 2 * NG + 1) s_Ew[tid] = p.wbin[tid - (NG + 1)];
   // 1/(E_{k+1}-E_k), read at the end of every rebin: wave-uniform values that the compiler kept in (and
   // spilled from) vector registers across the sorts
   __shared__ double rW[NG];
-  if (tid < NG) rW[tid] = 1.0 / (p.wbin_e[tid + 1] - p.wbin_e[tid]);
+  {
+    // Every table's loads go out together, at clamped indices, and only the LDS writes are predicated: written
+    // as five `if (tid < n) table[tid] = source[tid]` these were five memory round trips one after the other
+    // (each test's block waits for its own load) before a tile's first useful instruction.
+    static_assert(EXP2_N == OP_THREADS, "one table entry per thread");
+    const double v_wxy = p.wxy[tid & (NG * NG - 1)];
+    const double v_Ep = p.wbin_e_pad[min(tid, NG + 3)];
+    const double v_e2 = EXP2_TAB[tid];
+    const double v_e = p.wbin_e[min(tid, NG)], v_e1 = p.wbin_e[min(tid + 1, NG)];
+    const double v_w = p.wbin[min(max(tid - (NG + 1), 0), NG - 1)];
+    if (tid < NG * NG) s_wxy[tid] = v_wxy;
+    if (tid < NG + 4) s_E[tid] = v_Ep;
+    s_e2[tid] = v_e2;
+    if (tid < 2 * NG + 1) s_Ew[tid] = tid < NG + 1 ? v_e : v_w;
+    if (tid < NG) rW[tid] = 1.0 / (v_e1 - v_e);
+  }
   __syncthreads();
 
 #ifdef CLIMA_STAMPS
@@ -2246,6 +2256,19 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     }
   }
   const bool copies_band = gy == 0 && p.col_base == 0 && p.b_out == 0;  // this block copies the band optical depth out
+  // What the block's LDS table will hold -- the thread's entry of the exp table (solar) or the temperature /
+  // Planck value of the thread's level (IR) -- is requested with the loads above, not after them: behind
+  // their first use it was one more memory round trip before the block's first arithmetic.
+  const double *Tcol = p.T + co.col + (size_t)bz * p.b_T;   // (batched shared-opacity IR launches: blockIdx.z selects
+  const double *Tsfc = p.T_surface + co.col + (size_t)bz * p.b_Ts;   //  the temperature column; strides 0 otherwise)
+  double table_in;
+  if constexpr (solar) {
+    static_assert(EXP2_N == 64 * TSW_COLS, "one table entry per thread");
+    table_in = EXP2_TAB[threadIdx.x];
+  } else {
+    const int n = min((int)threadIdx.x, nz);
+    table_in = p.bplanck ? p.bplanck[n] : (n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);
+  }
 #pragma unroll
   for (int t = 0; t < L; t++) {
     const bool real = t >= pad;
@@ -2276,7 +2299,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     // ---- delta-Eddington (:38-40), quadrature coefficients (:43-44), lambda, Gamma (:50-51)
     // exp table of the zenith-angle loop (exp_tab)
     __shared__ double s_e2[EXP2_N];
-    for (int i = threadIdx.x; i < EXP2_N; i += blockDim.x) s_e2[i] = EXP2_TAB[i];
+    s_e2[threadIdx.x] = table_in;
     double taup[L], lam[L], zA[L], zB[L], zH[L];
     double tot = 0.0;
 #pragma unroll
@@ -2400,13 +2423,11 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   } else {
     Rsfc = p.has_hard_surface ? 1.0 - p.emissivity[ll] : 0.0;  // :186-190
     const double avg_freq = 0.5 * (p.freq[l] + p.freq[l + 1]);  // radiate.f90:64
-    // batched shared-opacity IR launches: blockIdx.z selects the temperature column (strides 0 otherwise)
-    const double *Tcol = p.T + co.col + (size_t)bz * p.b_T;
-    const double *Tsfc = p.T_surface + co.col + (size_t)bz * p.b_Ts;
     // Planck source at the levels (radiate.f90:65-69): the same for the block's g-point columns, so
     // each of the nz+1 values is computed once per block instead of L+1 times per lane of every wave
     double *sB = lds + (size_t)3 * NCOL * nl;
-    for (int n = threadIdx.x; n < nl; n += blockDim.x)  // TOA-first level
+    if ((int)threadIdx.x < nl) sB[threadIdx.x] = p.bplanck ? table_in : planck(avg_freq, table_in);  // TOA-first level
+    for (int n = threadIdx.x + blockDim.x; n < nl; n += blockDim.x)   // (more levels than threads)
       sB[n] = p.bplanck ? p.bplanck[n] : planck(avg_freq, n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);
     __syncthreads();
     // the L+1 faces of the slots (level a for every face of a zero-thickness slot)
