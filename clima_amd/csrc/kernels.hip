@@ -2261,14 +2261,16 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   // their first use it was one more memory round trip before the block's first arithmetic.
   const double *Tcol = p.T + co.col + (size_t)bz * p.b_T;   // (batched shared-opacity IR launches: blockIdx.z selects
   const double *Tsfc = p.T_surface + co.col + (size_t)bz * p.b_Ts;   //  the temperature column; strides 0 otherwise)
-  double table_in;
-  if constexpr (solar) {
-    static_assert(EXP2_N == 64 * TSW_COLS, "one table entry per thread");
-    table_in = EXP2_TAB[threadIdx.x];
-  } else {
+  static_assert(EXP2_N == 64 * TSW_COLS, "one table entry per thread");
+  const double e2_in = EXP2_TAB[threadIdx.x];
+  double table_in = 0.0;
+  if constexpr (!solar) {
     const int n = min((int)threadIdx.x, nz);
     table_in = p.bplanck ? p.bplanck[n] : (n == nz ? *Tsfc : Tcol[nz - 1 - min(n, nz - 1)]);
   }
+  // exp table (exp_tab): the solar zenith-angle loop's attenuations and both channels' exp(-lambda tau)
+  __shared__ double s_e2[EXP2_N];
+  s_e2[threadIdx.x] = e2_in;   // (every path has a barrier before its first exp_tab)
 #pragma unroll
   for (int t = 0; t < L; t++) {
     const bool real = t >= pad;
@@ -2297,9 +2299,6 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
 
   if constexpr (solar) {
     // ---- delta-Eddington (:38-40), quadrature coefficients (:43-44), lambda, Gamma (:50-51)
-    // exp table of the zenith-angle loop (exp_tab)
-    __shared__ double s_e2[EXP2_N];
-    s_e2[threadIdx.x] = table_in;
     double taup[L], lam[L], zA[L], zB[L], zH[L];
     double tot = 0.0;
 #pragma unroll
@@ -2416,7 +2415,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
         if (t >= pad) mine[3 * t] = cpb[t];
       }
       if (PAIRED && (t & 1)) X[t] = X[t - 1];
-      else X[t] = fexp(-lam[t] * taup[t]);  // :56
+      else X[t] = exp_tab(-lam[t] * taup[t], s_e2);  // :56
     }
     lvl0_dn = dir0;   // direct(1) = u0 (:73)
     lvl0_am = wsum;   // direct(1)/u0 = 1
@@ -2446,7 +2445,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
         const double gam2 = w0_in * (1.0 - gt_in);
         const double lam = sqrt_nr(gam1 * gam1 - gam2 * gam2);
         G[t] = gam2 * rcp_nr(gam1 + lam);
-        X[t] = fexp(-lam * tau_in);
+        X[t] = exp_tab(-lam * tau_in, s_e2);
         r_pair = rcp_nr(gam1 + gam2);
       }
       const double bpl_top = bpl[t], bpl_bot = bpl[t + 1];
