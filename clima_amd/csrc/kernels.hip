@@ -936,16 +936,24 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
     const double *wbin = s_Ew + NG + 1;
     double tb = 0.0;
     const size_t base = ((size_t)l * NG) * nz + nn;
+    const double scat = T.tausg + T.tausp + T.tausc;
+    if (p.write_w0) {
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        const double tau = T.tausg + T.taua + T.taup + tkv[g] + T.tauc;
+        double w0;
+        if (tau <= TAU_MIN) w0 = 0.0;
+        else w0 = fmin(MAX_W0, scat / tau);
+        st_opr<COHERENT>(&p.w0[oo + base + (size_t)g * nz], w0);
+      }
+    }
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       const double tau = T.tausg + T.taua + T.taup + tkv[g] + T.tauc;
-      double w0;
-      if (tau <= TAU_MIN) w0 = 0.0;
-      else w0 = fmin(MAX_W0, (T.tausg + T.tausp + T.tausc) / tau);
       st_opr<COHERENT>(&p.tau[oo + base + (size_t)g * nz], tau);
-      st_opr<COHERENT>(&p.w0[oo + base + (size_t)g * nz], w0);
       tb = tb + tau * wbin[g];
     }
+    st_opr<COHERENT>(&p.scat[oo + (size_t)l * nz + nn], scat);
     st_opr<COHERENT>(&p.tau_band[oo + (size_t)l * nz + nn], tb);
     st_opr<COHERENT>(&p.g[oo + (size_t)l * nz + nn], T.gt);
   };
@@ -2218,6 +2226,7 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
     if constexpr (RESK) return fast_exp(x, K);
     else return fast_exp(x);
   };
+  (void)fexp;   // (only the CLIMA_ZEN_EXP_POLY build still uses the polynomial exp here)
   auto planck = [&](double nu, double T) {
     if constexpr (RESK) return planck_fcn(nu, T, K);
     else return planck_fcn(nu, T);
@@ -2232,7 +2241,8 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   const int c = col_on ? c_raw : ng - 1;
   const double wcol = col_on ? p.wbin[c] : 0.0;  // g-point weight (radiate.f90:122-126)
   const double *tauL = p.tau + co.opr + ((size_t)l * ng + c) * nz;
-  const double *w0L = p.w0 + co.opr + ((size_t)l * ng + c) * nz;
+  // (w0_from_scat: the layer's scattering optical depth in place of the g-point's w0, see below)
+  const double *w0L = p.w0_from_scat ? p.scat + co.opr + (size_t)l * nz : p.w0 + co.opr + ((size_t)l * ng + c) * nz;
   const double *gL = p.g + co.opr + (size_t)l * nz;
   // layers [a,b) TOA-first; slot t holds layer a + t - pad when t >= pad, a zero-thickness layer otherwise
   const int a = PAIRED ? 2 * ((lane * (nz >> 1)) >> 6) : (lane * nz) >> WSH;
@@ -2271,6 +2281,13 @@ __device__ __forceinline__ void twostream_p_body(const TwoStreamParams &p, const
   // exp table (exp_tab): the solar zenith-angle loop's attenuations and both channels' exp(-lambda tau)
   __shared__ double s_e2[EXP2_N];
   s_e2[threadIdx.x] = e2_in;   // (every path has a barrier before its first exp_tab)
+  if (p.w0_from_scat) {
+    // the opacity tiles of this grid left w0 unwritten: w0 = min(MAX_W0, scat / tau) (types.f90:869-875;
+    // by the correctly rounded reciprocal, <= 1 ulp from the quotient the stored array would hold)
+#pragma unroll
+    for (int t = 0; t < L; t++)
+      w0_s[t] = tau_s[t] <= TAU_MIN ? 0.0 : dmin(MAX_W0, w0_s[t] * rcp_nr(tau_s[t]));
+  }
 #pragma unroll
   for (int t = 0; t < L; t++) {
     const bool real = t >= pad;
@@ -3093,9 +3110,6 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
     const int d0 = max((int)(t0 / OP_THREADS), 0), d1 = min((int)((t0 + nsrc - 1) / OP_THREADS), fp.n_op - 1);
     const int *done = fp.done + (size_t)cb * fp.bs.done;
     int ok = 1;
-    // the usual case is one or two tiles: both flags are fetched before either is looked at (one round
-    // trip to the device-coherent level instead of two)
-    int spins = 0;
     for (int d = d0; d <= d1 && ok; d++) {
       int spins = 0;
       while (__hip_atomic_load(&done[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fp.call_id) {
@@ -3224,6 +3238,7 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
     fp.sol_early = (int)std::min<long>(ts.n_sol, std::max<long>(0, first_round_bins - (long)(ts.sol_start + ts.sol_lo - op.bin_lo)));
   }
   ts.col_base = 0; ts.accumulate = hs ? 0 : 1;   // (a half-wave block holds all 8 g-points of its bin)
+  ts.scat = op.scat; ts.w0_from_scat = op.write_w0 ? 0 : 1;
   const size_t lds = sizeof(double) * (3 * TSW_COLS * (hs ? 2 : 1) + 1) * ((size_t)ts.nz + 1);
   const long items = (long)fp.ncol * (fp.n_op + fp.n_ts);
   const FusedKern k = ps ? fused_kernel_paired(ps) : hs ? fused_kernel_half(hs) : fused_kernel(op, fp.slots);
@@ -3426,6 +3441,21 @@ void launch_integrate(const IntegrateParams &p, hipStream_t s) {
   }
   hipLaunchKernelGGL(k_integrate_partial, dim3(p.nchunk, 4), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_integrate_final, dim3(1), dim3(1024), 0, s, p);
+}
+
+// w0 of every (bin, g-point, layer) from the layers' scattering optical depth, for calls whose fused grid left
+// the array unwritten (OpacityParams::write_w0 = 0): the expression of the opacity tile's store
+// (types.f90:869-875)
+__global__ __launch_bounds__(256) void k_w0_from_scat(const double *tau, const double *scat, double *w0, int nw, int ng, int nz) {
+  const size_t n = (size_t)nw * ng * nz;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t l = i / ((size_t)ng * nz), j = i % nz;
+    const double t = tau[i];
+    w0[i] = t <= TAU_MIN ? 0.0 : fmin(MAX_W0, scat[l * nz + j] / t);
+  }
+}
+void launch_w0_from_scat(const double *tau, const double *scat, double *w0, int nw, int ng, int nz, hipStream_t s) {
+  hipLaunchKernelGGL(k_w0_from_scat, dim3(2048), dim3(256), 0, s, tau, scat, w0, nw, ng, nz);
 }
 
 __global__ void k_f_total(int nl, const double *flux_n, double *f_total) {

@@ -171,7 +171,7 @@ struct Radtran {
   // opr: one block [tau | w0 | g | tau_band]; the four are views into it
   DevBuf<double> d_opr;
   size_t opr_count = 0;
-  DevBuf<double> d_tau, d_w0, d_g, d_tau_band;
+  DevBuf<double> d_tau, d_w0, d_g, d_tau_band, d_scat;
   bool opr_valid = false;
   // results
   DevBuf<double> d_small;     // flux_n[4*(nz+1)] | f_total[nz+1] | err flag slot: one D2H copy per call
@@ -180,6 +180,7 @@ struct Radtran {
   int *h_errflag = nullptr;
   std::vector<double> f_total;
   bool small_valid = false;
+  bool w0_valid = true;            // false after a fused call whose tiles left w0 unwritten (ensure_w0 materialises it)
   // sharding
   DevBuf<double> d_flux_part;  // this rank's partial level rows (d_flux_n is all-reduced in place)
   int shard_rank = 0, shard_world = 1;
@@ -554,6 +555,16 @@ size_t res_block_count(Radtran *r) {
   return (size_t)r->ir.nw * (2 * nl + nz) + (size_t)r->sol.nw * (3 * nl + nz);
 }
 
+// The stored w0 array is current (a fused call's tiles leave it to the two-stream part of the same grid:
+// whoever else wants it -- IR-only calls on the stored opacities, the batched IR kernel, radtran_opr_get --
+// gets it formed from tau and the layers' scattering optical depth first)
+void ensure_w0(Radtran *r) {
+  if (r->w0_valid) return;
+  launch_w0_from_scat(r->d_tau.p, r->d_scat.p, r->d_w0.p, r->nw, r->ng, r->nz, r->stream);
+  HIPCHK(hipGetLastError());
+  r->w0_valid = true;
+}
+
 void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool allow_fused = true,
                      const BatchCtx *bc = nullptr) {
   r->timer_calls++;
@@ -567,18 +578,18 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
   const int ncol = bc ? bc->ncol : 1;
   const int nsrc = bc ? nz : (r->col_override ? r->nsrc_override : r->nsrc);
   // where this call's optical properties and spectra live
-  double *o_tau = r->d_tau.p, *o_w0 = r->d_w0.p, *o_g = r->d_g.p, *o_tb = r->d_tau_band.p;
+  double *o_tau = r->d_tau.p, *o_w0 = r->d_w0.p, *o_g = r->d_g.p, *o_tb = r->d_tau_band.p, *o_sc = r->d_scat.p;
   double *ir_fup = r->wrk_ir.fup_a.p, *ir_fdn = r->wrk_ir.fdn_a.p, *ir_tb = r->wrk_ir.tau_band.p;
   double *sol_fup = r->wrk_sol.fup_a.p, *sol_fdn = r->wrk_sol.fdn_a.p, *sol_am = r->wrk_sol.amean.p, *sol_tb = r->wrk_sol.tau_band.p;
   if (bc) {
-    o_tau = bc->opr; o_w0 = o_tau + r->d_tau.n; o_g = o_w0 + r->d_w0.n; o_tb = o_g + r->d_g.n;
+    o_tau = bc->opr; o_w0 = o_tau + r->d_tau.n; o_g = o_w0 + r->d_w0.n; o_tb = o_g + r->d_g.n; o_sc = o_tb + r->d_tau_band.n;
     ir_fup = bc->res; ir_fdn = ir_fup + r->ir.nw * nl; ir_tb = ir_fdn + r->ir.nw * nl;
     sol_fup = ir_tb + (size_t)r->ir.nw * nz; sol_fdn = sol_fup + r->sol.nw * nl; sol_am = sol_fdn + r->sol.nw * nl;
     sol_tb = sol_am + r->sol.nw * nl;
   }
   auto ts_params = [&]() {
     TwoStreamParams ts = make_twostream_params(r, col, compute_solar);
-    ts.tau = o_tau; ts.w0 = o_w0; ts.g = o_g; ts.tau_band = o_tb;
+    ts.tau = o_tau; ts.w0 = o_w0; ts.g = o_g; ts.tau_band = o_tb; ts.scat = o_sc; ts.w0_from_scat = 0;
     ts.ir_fup_a = ir_fup; ts.ir_fdn_a = ir_fdn; ts.ir_tau_band = ir_tb;
     ts.sol_fup_a = sol_fup; ts.sol_fdn_a = sol_fdn; ts.sol_amean = sol_am; ts.sol_tau_band = sol_tb;
     // exact pairs in the column (and this call computes the opacities from it) -> exact pairs in opr
@@ -661,7 +672,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
 #ifdef CLIMA_STAMPS
     op.stamps = r->d_stamps.p;
 #endif
-    op.tau = o_tau; op.w0 = o_w0; op.g = o_g; op.tau_band = o_tb;
+    op.tau = o_tau; op.w0 = o_w0; op.g = o_g; op.tau_band = o_tb; op.scat = o_sc; op.write_w0 = 1;
     if (bc || (r->fused && allow_fused && (pre_zeroed || whole_stores) && !op.coop)) {
       TwoStreamParams tsf = ts_params();
       if (fused_supported(op, tsf) && (pre_zeroed || whole_stores)) {
@@ -671,9 +682,15 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
         fp.call_id = pp.call_id; fp.max_spins = r->fused_max_spins;
         fp.done = bc ? bc->done : r->d_done.p; fp.timeout_flag = r->d_err.p + 1;
         KernelTimer t(r, 1);
+        // the fused grid's two-stream part forms w0 from the layers' scattering optical depth itself: the
+        // tiles leave the 8 nw nz values unwritten (26 MB per config-2 call neither stored nor read back);
+        // ensure_w0() materialises them if something else asks (CLIMA_HIP_W0_SCAT=0: always written)
+        static const bool w0_scat = [] { const char *e = getenv("CLIMA_HIP_W0_SCAT"); return !(e && e[0] == '0'); }();
+        op.write_w0 = w0_scat ? 0 : 1;
         fused_done = launch_fused(op, tsf, fp, r->stream);
         HIPCHK(hipGetLastError());
         t.stop();
+        if (!fused_done) op.write_w0 = 1;
       }
     }
     if (bc && !fused_done) throw HipFail{"internal: a one-launch batch needs the fused grid"};
@@ -686,6 +703,9 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
       t.stop();
     }
     r->opr_valid = true;
+    if (!bc) r->w0_valid = op.write_w0 != 0;
+  } else if (!bc) {
+    ensure_w0(r);   // this call's two-stream kernels read the stored optical properties
   }
   r->last_cs = compute_solar;
   if (compute_solar) r->solar_id = r->call_id;
@@ -1271,10 +1291,11 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
 #ifdef CLIMA_STAMPS
   r->d_stamps.alloc(64 + 2 * 8192); r->d_stamps.zero();
 #endif
-  r->opr_count = (size_t)2 * nw * ng * nz + (size_t)2 * nw * nz;
+  r->opr_count = (size_t)2 * nw * ng * nz + (size_t)3 * nw * nz;
   r->d_opr.alloc(r->opr_count); r->d_opr.zero();
   r->d_tau.view(r->d_opr.p, (size_t)nw * ng * nz); r->d_w0.view(r->d_tau.p + r->d_tau.n, (size_t)nw * ng * nz);
   r->d_g.view(r->d_w0.p + r->d_w0.n, (size_t)nw * nz); r->d_tau_band.view(r->d_g.p + r->d_g.n, (size_t)nw * nz);
+  r->d_scat.view(r->d_tau_band.p + r->d_tau_band.n, (size_t)nw * nz);
   auto mk = [&](WrkObj &wk, int which, int nwc) {  // clima_radtran.f90:199-214
     wk.parent = r; wk.which = which;
     wk.fup_a.alloc((size_t)(nz + 1) * nwc); wk.fdn_a.alloc((size_t)(nz + 1) * nwc);
@@ -1338,6 +1359,7 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   if (r->shard_world != 1) { set_err(err, "radiate_ir_batch is not available on a bin-sharded handle"); return; }
   TRY
   upload_fields(r);
+  ensure_w0(r);
   const int nz = r->nz, nl = nz + 1, n = *ncol, nw_ir = r->ir.nw;
   const int CH = std::min(n, 64);  // columns per launch: bounds the per-column spectra held in HBM
   const int nchunk = integrate_chunks(r->ir_n);
@@ -1773,6 +1795,7 @@ void radtran_opr_get(void *ptr, double *tau, double *w0, double *g, double *tau_
   GUARD(r, ptr, err);
   if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
   TRY
+  ensure_w0(r);
   HIPCHK(hipStreamSynchronize(r->stream));
   resolve_events(r);
   if (tau) HIPCHK(hipMemcpy(tau, r->d_tau.p, r->d_tau.n * sizeof(double), hipMemcpyDeviceToHost));

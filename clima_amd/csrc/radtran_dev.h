@@ -138,6 +138,11 @@ struct OpacityParams {
   const double *wbin_e_pad;               // wbin_e followed by +inf sentinels (edge stream of the rebin)
   ColumnDev col;
   double *tau, *w0, *g, *tau_band;        // opr
+  double *scat;                           // [nw][nz] scattering optical depth tausg + tausp + tausc of a layer (every g-point's
+                                          // w0 is min(MAX_W0, scat / tau)): written always
+  int write_w0;                           // 0: the two-stream part of the same fused grid forms w0 from scat itself, the
+                                          // 8 x nw x nz values are neither written nor read back (the host materialises
+                                          // them when something else asks for them)
   long long *stamps;                      // diagnostic build only (-DCLIMA_STAMPS); null otherwise
   int rebin_mode;                         // 0 window form (the weights fit the compiled crossing windows), 1 streaming,
                                           // 2 streaming with max(wxy) > min(wbin): an element may span several output edges
@@ -170,6 +175,8 @@ struct TwoStreamParams {
   int n_sol, sol_lo, n_ir, ir_lo;          // channel-local first bin of this launch
   int sol_start, ir_start;                 // channel -> opacity-bin offset (RTChannel%ind_start)
   const double *tau, *w0, *g, *tau_band;   // opr
+  const double *scat;                      // see OpacityParams
+  int w0_from_scat;                        // the layers' w0 = min(MAX_W0, scat / tau) instead of the stored array
   const double *wbin;
   const double *freq;                      // opacity grid [nw+1]
   // test hook (clima_test_two_stream): Planck values at the levels given directly [nz+1] TOA-first
@@ -265,6 +272,7 @@ void launch_scale(double *a, size_t n, double f, hipStream_t s);
 void launch_copy(double *dst, const double *src, size_t n, hipStream_t s);  // src may be pinned host memory
 void launch_test_rcp(const double *x, double *y, int n, hipStream_t s);
 void launch_test_wscan(const double *a, const double *b, double *out, int nwaves, hipStream_t s);
+void launch_w0_from_scat(const double *tau, const double *scat, double *w0, int nw, int ng, int nz, hipStream_t s);
 void launch_test_exp(const double *x, double *y, int n, hipStream_t s);
 void launch_test_exp_tab(const double *x, double *y, int n, int base10, hipStream_t s);
 

@@ -148,6 +148,32 @@ def test_bin_sharded_ir_only_step_does_not_recount_solar(small_tables):
     step(col2)
 
 
+def test_single_scattering_albedo_left_to_the_fused_grid_is_materialised_on_demand(nominal):
+    """The fused grid's opacity tiles do not write w0 (its two-stream part forms it from the layers' scattering
+    optical depth); whoever asks for it afterwards -- the optical-property accessor, an IR-only call on the
+    stored opacities -- gets the array formed by the expression of the tile's store: bitwise what the
+    separate launches (which do write it) leave."""
+    tb, r, col = nominal
+    assert r.fused
+    r.radiate(*col.args())
+    tau_f, w0_f, g_f, tb_f = r.opr()
+    r.radiate(*col.args(), compute_solar=False, compute_opacity=False)     # two-stream kernels on the stored arrays
+    ir_stored = np.array(r.wrk_ir.fup_n)
+    r.fused = False
+    try:
+        r.radiate(*col.args())
+        tau_u, w0_u, g_u, tb_u = r.opr()
+        r.radiate(*col.args(), compute_solar=False, compute_opacity=False)
+        ir_unfused = np.array(r.wrk_ir.fup_n)
+    finally:
+        r.fused = True
+    np.testing.assert_array_equal(tau_f, tau_u)
+    np.testing.assert_array_equal(w0_f, w0_u)
+    np.testing.assert_array_equal(g_f, g_u)
+    np.testing.assert_array_equal(ir_stored, ir_unfused)
+    assert 0.0 < w0_f.max() <= 0.99999
+
+
 def test_separate_launch_form_at_full_size(nominal):
     """config 2 with one launch per kernel (the form the fused grid replaces) gives the same TOA
     fluxes to rounding."""
