@@ -11,14 +11,18 @@ k-distribution species, synthetic tables: SURVEY.md 8(d)).  Inputs (tables and t
 column) are resident in HBM before the timed region starts.
 
 What the one JSON line carries (rank 0):
-  value          resident form: K calls enqueued back to back on the handle's stream, bracketed by
-                 barrier + synchronise; the MEDIAN of at least `--repeats` such K-step timings, and of as
-                 many as it takes to time ~0.3 s in all (a 20-step run is 2.5 ms: one timing is a sample
-                 of the clock ramp); their spread is in `repeats_calls_per_s`.
-  sync_api       the drop-in call of SURVEY.md 8(d) "Metric": `radtran_toa_fluxes_wrapper` with host
-                 arrays in, ISR / OLR out, one stream synchronise per call (PCIe inclusive); median,
-                 p10, p90 over >= 30 calls.  This is what a Fortran / Python caller of `TOA_fluxes`
-                 sees, and what `cpu_baseline` is comparable with.
+  value          = `pipelined_calls_per_s`: the driver's contract -- K calls enqueued back to back on the
+                 handle's stream, bracketed by barrier + synchronise, inputs resident; the MEDIAN of at
+                 least `--repeats` such K-step timings, and of as many as it takes to time ~0.3 s in all
+                 (a 20-step run is 2.5 ms: one timing is a sample of the clock ramp); their spread is in
+                 `repeats_calls_per_s`.  It is NOT the per-call latency of SURVEY.md 8(d) "Metric"; those are:
+  resident_sync  one `radiate_resident` + `synchronize` per call (column in HBM, one host round trip per
+                 call), timed call by call inside the library; median, p10, p90 over 200 calls.
+  sync_api_c     the drop-in call of SURVEY.md 8(d) "Metric": `radtran_toa_fluxes_wrapper` with host
+                 arrays in, ISR / OLR out, one stream synchronise per call (PCIe inclusive), timed call by
+                 call INSIDE the library (what a Fortran / C caller of `TOA_fluxes` sees, and what
+                 `cpu_baseline` is comparable with); median, p10, p90 over 200 calls.
+  sync_api       the same call through the Python ctypes mirror (adds the foreign-function layer's ~14 us).
   roofline       dominant kernel, HIP events on the library's stream inside the timed region;
                  `fp64_issue_frac` = VALU instructions per launch (PMC pass under profiles/) x 4
                  cycles / (1024 SIMDs x 2.4 GHz) / kernel time; `traffic` from the PMC pass.  Both PMC
@@ -29,7 +33,11 @@ What the one JSON line carries (rank 0):
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the spectral bins of the SAME call are
 sharded over the ranks (work-balanced contiguous ranges) and every step ends with one RCCL
-all-reduce of the 4*(nz+1) partial level fluxes -- strong scaling of one call.
+all-reduce of the 4*(nz+1) partial level fluxes -- strong scaling of one call.  The collective is the
+LIBRARY's own (radtran_comm_init_rank: ncclAllReduce on the handle's stream inside radiate_resident);
+torch.distributed only launches the ranks, hands the communicator id round and takes the maximum of the
+ranks' timings.  CLIMA_BENCH_TORCH_ALLREDUCE=1 selects round 2's form (torch's all_reduce on a tensor
+aliasing the library's buffer) as a cross-check.
 
 --config 3 (EarlyMars, CIA-heavy, 200 layers), 4 (1024 perturbed columns through
 radtran_toa_fluxes_batch: columns/s; with N > 1 every rank takes 1024/N columns, no collective) and
@@ -137,20 +145,27 @@ def main():
     if cfg == 4:
         return config4(args, rad, tables, nz, nzen, world, rank, dist_on, dist, torch, json_fd)
 
+    torch_ar = os.environ.get("CLIMA_BENCH_TORCH_ALLREDUCE") == "1"
     if dist_on:
-        rad.set_bin_shard(rank, world)
+        if torch_ar:
+            rad.set_bin_shard(rank, world)
+        else:
+            # the library's own step: rank 0 draws the communicator id, torch.distributed hands it round
+            ids = [Radtran.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            rad.comm_init_rank(world, rank, ids[0])
         fake = os.environ.get("CLIMA_BENCH_FAKE_SHARD")   # "rank,world": rehearse one rank's share of an N-GPU step on one GPU
         if fake and world == 1:
             rad.set_bin_shard(*[int(x) for x in fake.split(",")])
     rad.upload_column(*col.args())
-    flux = rad.flux_tensor() if dist_on else None
+    flux = rad.flux_tensor() if (dist_on and torch_ar) else None
     # The all-reduce is ordered against the library's kernels on the device: the library's HIP
     # stream is made torch's current stream for the collective, so RCCL's stream waits for the
     # partial fluxes and the library stream waits for the reduced ones -- no host round trip
     # inside a step.  CLIMA_BENCH_HOST_SYNC=1 selects the plain host-synchronised form.
     host_sync = os.environ.get("CLIMA_BENCH_HOST_SYNC") == "1"
     lib_stream = None
-    if dist_on and not host_sync:
+    if dist_on and torch_ar and not host_sync:
         try:
             lib_stream = torch.cuda.ExternalStream(rad.stream())
         except Exception as e:  # same torch build on every rank: all of them take the same branch
@@ -158,8 +173,8 @@ def main():
             host_sync = True
 
     def step():
-        rad.radiate_resident()
-        if dist_on:
+        rad.radiate_resident()                    # with a communicator: shard -> kernels -> ncclAllReduce, all on the library's stream
+        if dist_on and torch_ar:
             if host_sync:
                 rad.synchronize()                 # library stream -> host
                 dist.all_reduce(flux)             # RCCL over xGMI: 4*(nz+1) doubles
@@ -219,10 +234,23 @@ def main():
     rad.profile_stride(1)
     rad.profile(False)
 
-    # ---- the synchronous drop-in call (host arrays in, ISR / OLR out, one stream sync per call)
-    sync_api = None
+    # ---- per-call latencies (SURVEY.md 8(d) "Metric"): one host round trip per call
+    def _stats(ts, what):
+        ts = np.asarray(ts, dtype=float)
+        return {"what": what, "calls_per_s": 1e6 / float(np.median(ts)), "us_median": float(np.median(ts)),
+                "us_p10": float(np.percentile(ts, 10)), "us_p90": float(np.percentile(ts, 90)), "n": int(len(ts))}
+
+    sync_api = sync_api_c = resident_sync = None
+    a = col.args()
+    rad.bench_resident_sync(20)
+    resident_sync = _stats(rad.bench_resident_sync(200),
+                           "radtran_radiate_resident + radtran_synchronize per call (column resident in HBM, one host round trip "
+                           "per call%s), timed call by call inside the library" % (", all-reduce included" if dist_on else ""))
     if not dist_on:
-        a = col.args()
+        rad.bench_toa_fluxes(20, *a)
+        sync_api_c = _stats(rad.bench_toa_fluxes(200, *a),
+                            "radtran_toa_fluxes_wrapper: host arrays in, ISR/OLR out, one stream synchronise per call (PCIe "
+                            "inclusive), timed call by call inside the library (what a Fortran / C host sees)")
         for _ in range(10):
             rad.TOA_fluxes(*a)
         ts = []
@@ -230,10 +258,7 @@ def main():
             t0 = time.perf_counter()
             rad.TOA_fluxes(*a)
             ts.append(time.perf_counter() - t0)
-        ts = np.array(ts) * 1e6
-        sync_api = {"what": "radtran_toa_fluxes_wrapper: host arrays in, ISR/OLR out, one stream synchronise per call (PCIe inclusive), through the ctypes mirror",
-                    "calls_per_s": 1e6 / float(np.median(ts)), "us_median": float(np.median(ts)),
-                    "us_p10": float(np.percentile(ts, 10)), "us_p90": float(np.percentile(ts, 90)), "n": len(ts)}
+        sync_api = _stats(np.array(ts) * 1e6, "the same call through the ctypes mirror clima_amd.radtran.Radtran.TOA_fluxes")
         rad.upload_column(*a)
 
     # ---- companion figure for N > 1 (not `value`): the column-parallel form of config 4 --
@@ -256,13 +281,13 @@ def main():
         del rad2
 
     # ---- parity of what was just timed (rank 0 checks OLR against the oracle)
-    if dist_on:
+    if dist_on and torch_ar:
         isr = float((flux[3 * (nz + 1) + nz] - flux[2 * (nz + 1) + nz]).item())
         olr = -float((flux[1 * (nz + 1) + nz] - flux[0 * (nz + 1) + nz]).item())
     else:
-        rad.radiate_resident()
+        step()
         rad.synchronize()
-        w_ir, w_sol = rad.wrk_ir, rad.wrk_sol
+        w_ir, w_sol = rad.wrk_ir, rad.wrk_sol    # with a communicator: the reduced rows, the same on every rank
         olr = -(w_ir.fdn_n[nz] - w_ir.fup_n[nz])
         isr = w_sol.fdn_n[nz] - w_sol.fup_n[nz]
 
@@ -287,7 +312,18 @@ def main():
         issue = None
         if pmc and dur > 0 and pmc.get("SQ_INSTS_VALU"):
             issue = pmc["SQ_INSTS_VALU"] * F64_CYCLES / (SIMDS * CLOCK_GHZ * 1e9) / dur
-        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": b_alg / dur / 1e9 if dur > 0 else 0.0,
+        # what actually bounds the kernel: wave64 f64 issue.  At one instruction per SIMD per
+        # 4 cycles the kernel's VALU instructions alone take valu*4/(1024*2.4e9) s: that is the floor of THIS
+        # instruction stream, and the fraction of the HBM roof it would reach
+        practical = None
+        if pmc and pmc.get("SQ_INSTS_VALU"):
+            floor_s = pmc["SQ_INSTS_VALU"] * F64_CYCLES / (SIMDS * CLOCK_GHZ * 1e9)
+            practical = {"floor_us": floor_s * 1e6, "hbm_frac_at_floor": (b_alg / floor_s / 1e9) / HBM_PEAK_GBS,
+                         "what": "the kernel's %.4g VALU instructions per launch at one wave64 f64 instruction per SIMD per 4 cycles "
+                                 "(1024 SIMDs, 2.4 GHz): no launch of this instruction stream can be shorter, so the 40 %% HBM "
+                                 "target of north_star is out of reach for this algorithm" % pmc["SQ_INSTS_VALU"]}
+        roofline = {"bound": "hbm", "practical_bound": "fp64_valu", "practical_ceiling": practical,
+                    "kernel": "k_" + dom, "achieved": b_alg / dur / 1e9 if dur > 0 else 0.0,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (b_alg / dur / 1e9) / HBM_PEAK_GBS if dur > 0 else 0.0,
                     "traffic": (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None,
@@ -296,6 +332,9 @@ def main():
                     "fp64_issue_source": ("SQ_INSTS_VALU = %.4g per launch (%s) x %g cycles / (%d SIMDs x %g GHz) / kernel time"
                                           % (pmc["SQ_INSTS_VALU"], pmc_src, F64_CYCLES, SIMDS, CLOCK_GHZ)) if issue else pmc_src,
                     "algorithmic_bytes": b_alg, "kernel_us": per_kernel_us,
+                    "kernel_us_source": "%s: HIP events on every %d-th launch of the timed region; the others: a separate pass of "
+                                        "%d fully instrumented calls before it (an event pair per kernel drains the queue, so "
+                                        "those figures are a few us above the profiler's)" % (dom, EVENT_STRIDE, min(max(args.steps, 1), 50)),
                     "whole_call_frac": (b_alg / (dt / args.steps) / 1e9) / HBM_PEAK_GBS}
         out = {"metric": "radiate() calls/sec", "value": value, "unit": "calls/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -304,7 +343,11 @@ def main():
                "config": {"workload": what,
                           "parallelism": ("bins sharded over %d GPUs + 1 all-reduce of %d f64" % (world, 4 * (nz + 1)))
                           if world > 1 else "1 GPU"},
-               "value_is": "median of %d repeats of the %d-step loop, resident inputs, calls enqueued back to back" % (len(dts), args.steps),
+               "value_is": "pipelined_calls_per_s: median of %d repeats of the %d-step loop, resident inputs, calls enqueued back to "
+                           "back, one synchronise per loop (the driver's contract); per-call latencies are in resident_sync / sync_api_c" % (len(dts), args.steps),
+               "pipelined_calls_per_s": value,
+               "collective": (("library: ncclAllReduce on the handle's stream (radtran_comm_init_rank)" if not torch_ar else
+                               "torch.distributed all_reduce on an aliased tensor") if dist_on else None),
                "repeats_calls_per_s": {"n": len(dts), "min": args.steps / max(dts), "p10": args.steps / float(np.percentile(dts, 90)),
                                        "median": args.steps / dt, "p90": args.steps / float(np.percentile(dts, 10)),
                                        "max": args.steps / min(dts), "first": args.steps / dts[0]},
@@ -313,15 +356,21 @@ def main():
                                "N_T_table": nodes["N_T_full"], "bytes_distinct_nodes": b_alg,
                                "bytes_whole_tables": b_alg_full,
                                "frac_whole_tables": (b_alg_full / dur / 1e9) / HBM_PEAK_GBS if dur > 0 else 0.0}}
+        if resident_sync is not None:
+            out["resident_sync"] = resident_sync
+        if sync_api_c is not None:
+            out["sync_api_c"] = sync_api_c
         if sync_api is not None:
             out["sync_api"] = sync_api
         if col_par is not None:
             out["column_parallel"] = col_par
-        if not args.no_cpu_baseline and world == 1:
-            out.update(cpu_baseline(tables, col, nz, nzen, albedo, olr, rad, 0.4286 if cfg == 3 else None))
+        if not args.no_cpu_baseline:   # rank 0, every N (the other ranks wait at the final barrier)
+            out.update(cpu_baseline(tables, col, nz, nzen, albedo, olr, rad if world == 1 else None, 0.4286 if cfg == 3 else None))
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist_on:
+        dist.barrier()
+        rad.comm_destroy()
         dist.destroy_process_group()
 
 

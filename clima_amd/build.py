@@ -15,6 +15,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # a scratch load.  The unrolled opacity tile has more uses than that.
 LLVM_FLAGS = ["-mllvm", "-instcombine-max-copied-from-constant-users=100000"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"] + LLVM_FLAGS
+# RCCL: the bin-sharded step's all-reduce is issued by the library itself (radtran_comm_init_rank).  In a process
+# that imported torch first, the loader resolves librccl.so.1 to the copy torch has already mapped (same SONAME).
+LIBS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
 
 
 def is_stale():
@@ -24,14 +27,15 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not (force or is_stale()):
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """`out`: write another build of the library there (A/B variants, tools/gpu_ab.sh) instead of LIB."""
+    if not (force or is_stale() or out):
         return LIB
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out or LIB] + LIBS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 FORTRAN_DIR = os.path.join(_HERE, "fortran")
@@ -59,6 +63,9 @@ def build_fortran_shim(verbose=False):
 
 
 if __name__ == "__main__":
+    # python -m clima_amd.build [--force] [-D...] [out=variants/lib_x.so]
+    _out = next((a[4:] for a in sys.argv[1:] if a.startswith("out=")), None)
     build(force="--force" in sys.argv, verbose=True,
-          extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
-    build_fortran_shim(verbose=True)
+          extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"], out=_out)
+    if not _out:
+        build_fortran_shim(verbose=True)

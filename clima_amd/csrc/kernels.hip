@@ -3100,10 +3100,16 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   const bool solar = bl < ts.n_sol;
   const int ll = solar ? ts.sol_lo + bl : ts.ir_lo + (bl - ts.n_sol);
   const int l = (solar ? ts.sol_start : ts.ir_start) + ll;
-  __shared__ int s_ok;
 #ifdef CLIMA_STAMPS
   if (op.stamps && threadIdx.x == 0 && cb == 0) op.stamps[64 + 2 * 3128 + 3 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
+  // The wait for the opacity tiles that cover this item's bin: thread 0 polls, everyone meets at the barrier.
+  // (Round 3, measured on config 2: with NO wait at all -- an unsafe build, for the timing only -- the call takes
+  // 90.45 instead of 91.40 us, so the whole hand-off is worth under 1 us; a form in which every wave issued its
+  // loads together with the flag reads and validated them against a completion time stamp of the tile
+  // (s_memrealtime), one device round trip instead of two, kept its first loads in 1200 of 1200 blocks and was
+  // 1.2 us SLOWER: 92.4 us.  A two-stream block's start-up latency is hidden by the other wave of its SIMD.)
+  __shared__ int s_ok;
   if (threadIdx.x == 0) {
     const int nsrc = op.col.meta[2 * (size_t)cb * fp.bs.col];
     const long t0 = (long)(l - op.bin_lo) * nsrc;
@@ -3247,9 +3253,12 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
   return true;
 }
 
-bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s, bool half) {
+bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s, bool half, bool paired) {
   if (ts.ng != 8 || slots < 2 || slots > 8 || (ts.nz + 63) / 64 > slots || ts.nzen > MAX_ZEN) return false;
-  if (half && (slots < 3 || slots > 7 || (ts.nz + 31) / 32 > slots)) return false;
+  if (half && (paired || slots < 3 || slots > 7 || (ts.nz + 31) / 32 > slots)) return false;
+  // the paired form: chunks are cut at pair boundaries, so a lane holds 2 ceil((nz/2)/64) slots at most
+  if (paired && ((ts.nz & 1) || (slots & 1) || 2 * ((ts.nz / 2 + 63) / 64) > slots)) return false;
+  ts.paired = paired ? 1 : 0;
   OpacityParams op;
   memset(&op, 0, sizeof(op));
   op.nz = ts.nz;
@@ -3263,7 +3272,7 @@ bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta
   fp.sol_early = ts.n_sol;
   ts.col_base = 0; ts.accumulate = half ? 0 : 1;
   const size_t lds = sizeof(double) * (3 * TSW_COLS * (half ? 2 : 1) + 1) * ((size_t)ts.nz + 1);
-  const FusedKern k = half ? fused_kernel_half(slots) : fused_kernel(op, slots);
+  const FusedKern k = half ? fused_kernel_half(slots) : paired ? fused_kernel_paired(slots) : fused_kernel(op, slots);
   if (lds > 48 * 1024 && !ensure_max_lds((const void *)k, 64 * 1024)) return false;
   hipLaunchKernelGGL(k, dim3(fp.n_ts), dim3(OP_THREADS), lds, s, op, ts, fp);
   return true;
@@ -3305,6 +3314,10 @@ __global__ __launch_bounds__(256) void k_integrate_partial(IntegrateParams p) {
 
 __global__ __launch_bounds__(1024) void k_integrate_final(IntegrateParams p) {
   const int nl = p.nz + 1;
+  if (p.timeout_out && threadIdx.x == 0) {   // see k_integrate_one
+    const int t = *p.timeout_flag;
+    *p.timeout_out = (t == p.id_opr ? 1.0 : 0.0) + (t == p.id_sol ? 1024.0 : 0.0);
+  }
   for (int t = threadIdx.x; t < 4 * nl; t += blockDim.x) {
     const int a = t / nl, i = t - a * nl;
     if (a >= 2 && !p.do_solar) {
@@ -3385,6 +3398,10 @@ __global__ __launch_bounds__(INT_LV * INT_CG) void k_integrate_one(IntegratePara
   const int nl = p.nz + 1;
   const int lv = threadIdx.x % INT_LV, cg = threadIdx.x / INT_LV;
   const int i = blockIdx.x * INT_LV + lv;
+  if (p.timeout_out && a == 0 && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    const int t = *p.timeout_flag;   // the fused grid of this call has drained: the word is final
+    *p.timeout_out = (t == p.id_opr ? 1.0 : 0.0) + (t == p.id_sol ? 1024.0 : 0.0);
+  }
   if (sol && !p.do_solar) {
     // solar rows keep the last solar call's values (clima_radtran.f90:286-289).  On a bin-sharded
     // handle flux_n is the all-reduce buffer and holds REDUCED rows by now: this rank's partial

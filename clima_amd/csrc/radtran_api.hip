@@ -7,6 +7,10 @@
 #include "../../include/clima_radtran_hip.h"
 #include "radtran_dev.h"
 
+#include <rccl/rccl.h>   // the bin-sharded step's one collective; backend "nccl" on ROCm IS RCCL
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -43,6 +47,12 @@ struct HipFail {
     hipError_t e_ = (call);                                                                  \
     if (e_ != hipSuccess)                                                                    \
       throw HipFail{std::string("HIP error in " #call ": ") + hipGetErrorString(e_)};        \
+  } while (0)
+#define NCCLCHK(call)                                                                        \
+  do {                                                                                       \
+    ncclResult_t e_ = (call);                                                                \
+    if (e_ != ncclSuccess)                                                                   \
+      throw HipFail{std::string("RCCL error in " #call ": ") + ncclGetErrorString(e_)};      \
   } while (0)
 
 template <class T>
@@ -163,6 +173,8 @@ struct Radtran {
   hipEvent_t ev_upload = nullptr;   // marks the end of the last column copy out of the pinned staging buffer
   bool upload_pending = false;
   int call_id = 0, checked_id = 0;  // opacity passes enqueued / already checked for device errors
+  long upload_id = 0, opr_upload_id = 0;   // columns uploaded so far / the upload the stored opacities were computed from
+  std::string deferred_err;         // a failure met inside a getter without an `err` argument: reported by the next call that has one
   // fused hand-off (k_fused): bound of a two-stream block's wait, the last timed-out pass already
   // handled, the pass of the last solar computation, flags of the last call, re-issued calls so far
   int fused_max_spins = 400000, checked_timeout = 0, solar_id = 0, fused_fallbacks = 0;
@@ -184,6 +196,12 @@ struct Radtran {
   // sharding
   DevBuf<double> d_flux_part;  // this rank's partial level rows (d_flux_n is all-reduced in place)
   int shard_rank = 0, shard_world = 1;
+  // the library's own multi-GPU step (radtran_comm_init_rank): with a communicator every radiate() ends with ONE
+  // ncclAllReduce of the 4 (nz+1) partial level fluxes (+ one status word) on the handle's stream
+  ncclComm_t comm = nullptr;
+  int comm_n = 1, comm_rank = 0, device = 0;
+  long comm_reduces = 0;       // all-reduces enqueued so far (tests)
+  double comm_status = 0.0;    // the reduced status word of the last fetched step (see IntegrateParams::timeout_out)
   int op_lo = 0, op_n = 0, ir_lo = 0, ir_n = 0, sol_lo = 0, sol_n = 0;
   // stream + profiling
   hipStream_t stream = nullptr;
@@ -220,6 +238,7 @@ struct Radtran {
     if (h_col) (void)hipHostFree(h_col);
     if (h_small) (void)hipHostFree(h_small);
     if (ev_upload) (void)hipEventDestroy(ev_upload);
+    if (comm) (void)ncclCommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
     magic = 0;
   }
@@ -704,6 +723,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     }
     r->opr_valid = true;
     if (!bc) r->w0_valid = op.write_w0 != 0;
+    if (!bc && !r->col_override) r->opr_upload_id = r->upload_id;
   } else if (!bc) {
     ensure_w0(r);   // this call's two-stream kernels read the stored optical properties
   }
@@ -738,7 +758,21 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
   ip.f_total = r->shard_world == 1 ? (r->ftot_override ? r->ftot_override : r->d_f_total.p) : nullptr;
   ip.nchunk = integrate_chunks(std::max(r->ir_n, r->sol_n));
   ip.partial = r->d_partial.p;
+  const bool reduce = r->comm && !bc && !r->col_override;
+  if (reduce) {
+    // the status word rides on the all-reduce in the slot behind the four level rows (f_total's first element:
+    // on such a handle f_total is formed on the host from the REDUCED rows, fetch_small)
+    ip.f_total = nullptr;
+    ip.timeout_out = r->d_small.p + 4 * nl; ip.timeout_flag = r->d_err.p + 1;
+    ip.id_opr = r->call_id; ip.id_sol = r->solar_id;
+  }
   { KernelTimer t(r, 3); launch_integrate(ip, r->stream); HIPCHK(hipGetLastError()); t.stop(); }
+  if (reduce) {
+    // the step's single collective (src/radtran/clima_radtran_radiate.f90:184-192 summed over the bins of all
+    // ranks): in place, on the handle's stream, no host round trip
+    NCCLCHK(ncclAllReduce(r->d_small.p, r->d_small.p, 4 * nl + 1, ncclDouble, ncclSum, r->comm, r->stream));
+    r->comm_reduces++;
+  }
   r->small_valid = false;
 }
 
@@ -751,6 +785,7 @@ void fetch_small(Radtran *r) {
     HIPCHK(hipMemcpyAsync(r->h_small, r->d_small.p, sizeof(double) * (5 * nl + 1), hipMemcpyDeviceToHost, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream));
     resolve_events(r);
+    if (r->comm) r->comm_status = r->h_small[4 * nl];
     if (r->col_override || !r->column_loaded || !recover_fused_timeout(r)) break;  // re-issued unfused: fetch again
   }
   // f_total from the four level rows (clima_radtran.f90:287); the one-launch integration leaves it
@@ -793,6 +828,7 @@ void do_upload(Radtran *r, double T_surface, const double *T, const double *P, c
     std::memcpy(hp + (size_t)nz * r->np, radii, sizeof(double) * (size_t)nz * r->np);
   }
   r->column_has_particles = (pdens && radii);
+  r->upload_id++;
   {
     int *meta = reinterpret_cast<int *>(h + r->meta_ofs);
     r->nsrc = build_meta(r, T, P, dz, dens, pdens, radii, r->column_has_particles, meta);
@@ -821,15 +857,34 @@ void do_upload(Radtran *r, double T_surface, const double *T, const double *P, c
 // computed again through the separate launches.  h_errflag[1] must be current (fetch_small /
 // radtran_synchronize).  Opacities and IR results are stale when the last opacity pass timed out,
 // the solar results when the pass of the last solar computation did.
+const char *const REPLACED_MSG = "The fused opacity/two-stream hand-off of an earlier opacity pass timed out and the column has "
+                                 "been replaced since: repeat the steps from that opacity pass on.";
 bool recover_fused_timeout(Radtran *r) {
+  if (r->comm) {
+    // With a communicator the partial rows are already summed when the host looks: the step is repeated by
+    // EVERY rank -- each learns of any rank's expired wait from the reduced status word -- through the separate
+    // launches, collective included.  The repeat's own status word is 0 (its passes have new ids).
+    const double st = r->comm_status;
+    if (!(st > 0.0)) return false;
+    r->comm_status = 0.0;
+    r->checked_timeout = r->call_id;
+    if (std::fmod(st, 1024.0) > 0.0 && r->upload_id != r->opr_upload_id) throw HipFail{REPLACED_MSG};
+    r->fused_fallbacks++;
+    enqueue_radiate(r, st >= 1024.0 || r->last_cs, true, false);
+    return true;
+  }
   const int t = r->h_errflag[1];
   if (t <= r->checked_timeout) return false;
   r->checked_timeout = r->call_id;
   const bool stale_opr = t == r->call_id, stale_sol = t == r->solar_id;
   if (!stale_opr && !stale_sol) return false;
-  if (r->shard_world > 1)  // the partial rows have been all-reduced already: this step cannot be redone here
-    throw HipFail{"The fused opacity/two-stream hand-off timed out on a bin-sharded handle; repeat the step "
-                  "(radtran_fused_set(0) selects the separate launches)."};
+  if (r->shard_world > 1)  // reduced by the CALLER (no communicator on the handle): this step cannot be redone here
+    throw HipFail{"The fused opacity/two-stream hand-off timed out on a bin-sharded handle whose all-reduce is the caller's; "
+                  "repeat the step (radtran_fused_set(0) selects the separate launches; with radtran_comm_init_rank the "
+                  "library repeats it itself)."};
+  // the stored opacities came from a column that has been replaced since (upload A, opacity pass, upload B, a
+  // compute_opacity = .false. pass): computing them again from column B is not what the caller asked for
+  if (stale_opr && r->upload_id != r->opr_upload_id) throw HipFail{REPLACED_MSG};
   r->fused_fallbacks++;
   enqueue_radiate(r, stale_sol || r->last_cs, true, false);
   return true;
@@ -846,10 +901,27 @@ bool surface_device_error(Radtran *r, char *err) {
   return false;
 }
 
+// Everything enqueued so far has run, and a fused hand-off that timed out has been repaired: after this the
+// device buffers hold the call's results (what fetch_small does for the level rows; the per-bin spectra and the
+// optical properties are read out after this)
+void settle(Radtran *r) {
+  for (int pass = 0; pass < 2; pass++) {
+    HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, r->stream));
+    if (r->comm && !r->small_valid)   // the reduced status word (the rows themselves are fetched when they are read)
+      HIPCHK(hipMemcpyAsync(&r->comm_status, r->d_small.p + 4 * (r->nz + 1), sizeof(double), hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    resolve_events(r);
+    if (r->col_override || !r->column_loaded || !recover_fused_timeout(r)) break;
+  }
+}
+
+void defer_err(Radtran *r, const std::string &msg) {
+  if (r && r->deferred_err.empty()) r->deferred_err = msg;
+}
+
 void get2d(WrkObj *w, DevBuf<double> &buf, int dim1, int dim2, double *arr) {
   Radtran *r = w->parent;
-  HIPCHK(hipStreamSynchronize(r->stream));
-  resolve_events(r);
+  settle(r);
   size_t n = std::min((size_t)dim1 * dim2, buf.n);
   if (n) HIPCHK(hipMemcpy(arr, buf.p, n * sizeof(double), hipMemcpyDeviceToHost));
 }
@@ -1202,6 +1274,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   int dev_count = 0;
   HIPCHK(hipGetDeviceCount(&dev_count));
   if (dev_count < 1) throw HipFail{"no HIP device available: the Radtran hot path has no CPU fallback"};
+  HIPCHK(hipGetDevice(&r->device));
   HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&r->ev_upload, hipEventDisableTiming));
   if (const char *f = getenv("CLIMA_HIP_FUSED")) r->fused = atoi(f) != 0;
@@ -1507,14 +1580,33 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
     resolve_events(r);
   };
   run_all(true);
+  bool fell_back = false;
   if (r->h_errflag[1] >= first_call) {  // a fused hand-off wait expired in some column: the batch again, unfused
     r->fused_fallbacks++;
     run_all(false);
+    fell_back = true;
   }
   r->checked_timeout = r->call_id;
   r->small_valid = false;
   r->column_loaded = false;   // d_col does not hold the last column: a resident call needs an upload first
-  r->opr_valid = !one_launch;  // the one-launch form leaves the optical properties in the batch arena, not in the handle
+  // What the handle holds afterwards is the LAST column's, like after n single calls: its level rows (copied above),
+  // and its spectra / band optical depths -- the one-launch form left those in the batch arena (copied here);
+  // its optical properties stay in the arena (opr_valid false: an IR-only call needs a compute_opacity call first),
+  // unless the batch fell back to one call per column, which works in the handle's own buffers.
+  const bool in_arena = one_launch && !fell_back;
+  r->opr_valid = !in_arena;
+  if (in_arena) {
+    const double *res = r->d_res_arena.p + (size_t)((n - 1) % CH) * res_block_count(r);
+    const size_t nli = (size_t)r->ir.nw * nl, nls = (size_t)r->sol.nw * nl, nzi = (size_t)r->ir.nw * nz, nzs = (size_t)r->sol.nw * nz;
+    auto d2d = [&](DevBuf<double> &dst, const double *src, size_t cnt) {
+      HIPCHK(hipMemcpyAsync(dst.p, src, sizeof(double) * cnt, hipMemcpyDeviceToDevice, r->stream));
+    };
+    d2d(r->wrk_ir.fup_a, res, nli); d2d(r->wrk_ir.fdn_a, res + nli, nli); d2d(r->wrk_ir.tau_band, res + 2 * nli, nzi);
+    const double *rs = res + 2 * nli + nzi;
+    d2d(r->wrk_sol.fup_a, rs, nls); d2d(r->wrk_sol.fdn_a, rs + nls, nls); d2d(r->wrk_sol.amean, rs + 2 * nls, nls);
+    d2d(r->wrk_sol.tau_band, rs + 3 * nls, nzs);
+    HIPCHK(hipStreamSynchronize(r->stream));
+  }
   if (*r->h_errflag >= first_call) {
     r->checked_id = r->call_id;
     set_err(err, "Opacity computation failed in one or more wavelength bins.");  // clima_radtran_types.f90:773-776
@@ -1536,11 +1628,11 @@ void radtran_synchronize(void *ptr, char *err) {
   GUARD(r, ptr, err);
   if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
   TRY
-  for (int pass = 0; pass < 2; pass++) {
-    HIPCHK(hipMemcpyAsync(r->h_errflag, r->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, r->stream));
-    HIPCHK(hipStreamSynchronize(r->stream));
-    resolve_events(r);
-    if (!r->column_loaded || !recover_fused_timeout(r)) break;
+  settle(r);
+  if (!r->deferred_err.empty()) {   // a getter without an `err` argument met a failure since the last check
+    const std::string m = r->deferred_err;
+    r->deferred_err.clear();
+    throw HipFail{m};
   }
   surface_device_error(r, err);
   CATCH(err)
@@ -1605,6 +1697,40 @@ void radtran_toa_fluxes_wrapper(void *ptr, const double *T_surface, const int *d
   *OLR = -(r->h_small[1 * nl + nz] - r->h_small[0 * nl + nz]);
 }
 
+// Bench hook: `n` synchronous radtran_toa_fluxes_wrapper calls (host arrays in, ISR / OLR out, one stream
+// synchronise each) timed one by one with the host's steady clock INSIDE the library -- the figure a Fortran or C
+// caller of TOA_fluxes sees, without the ~14 us a ctypes call adds (SURVEY.md 8(d) "Metric").  us[n].
+void clima_bench_toa_fluxes(void *ptr, const int *n, const double *T_surface, const int *dim_T, const double *T,
+                            const int *dim_P, const double *P, const int *dim1_d, const int *dim2_d,
+                            const double *densities, const int *dim_dz, const double *dz, const int *has_particles,
+                            const int *dim1_p, const int *dim2_p, const double *pdensities, const int *dim1_r,
+                            const int *dim2_r, const double *radii, double *us, double *ISR, double *OLR, char *err) {
+  clear_err(err);
+  for (int i = 0; i < *n; i++) {
+    const int one = 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    radtran_toa_fluxes_wrapper(ptr, T_surface, dim_T, T, dim_P, P, dim1_d, dim2_d, densities, dim_dz, dz, has_particles,
+                               dim1_p, dim2_p, pdensities, dim1_r, dim2_r, radii, &one, &one, ISR, OLR, err);
+    us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (err && err[0]) return;
+  }
+}
+
+// Bench hook: `n` resident calls, each followed by its own radtran_synchronize (no PCIe for the column, one host
+// round trip per call), timed one by one inside the library.  us[n].
+void clima_bench_resident_sync(void *ptr, const int *n, double *us, char *err) {
+  clear_err(err);
+  const int one = 1;
+  for (int i = 0; i < *n; i++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    radtran_radiate_resident(ptr, &one, &one, err);
+    if (err && err[0]) return;
+    radtran_synchronize(ptr, err);
+    us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (err && err[0]) return;
+  }
+}
+
 void radtran_apply_radiation_enhancement(void *ptr, const double *rad_enhancement) {
   Radtran *r = as_rad(ptr);
   if (!r || r->state != 2) return;
@@ -1632,6 +1758,12 @@ void radtran_set_bin_shard(void *ptr, const int *rank, const int *world, char *e
   GUARD(r, ptr, err);
   if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
   if (*world < 1 || *rank < 0 || *rank >= *world) { set_err(err, "invalid shard (rank, world)"); return; }
+  // a communicator fixes the shard (rank, nranks) -- except a one-rank communicator, on which any shard may be
+  // rehearsed (one rank's share of an N-GPU step on one GPU: bench.py CLIMA_BENCH_FAKE_SHARD)
+  if (r->comm && r->comm_n > 1 && (*world != r->comm_n || *rank != r->comm_rank)) {
+    set_err(err, "the bin shard of a handle with a communicator is (rank, nranks) of the communicator");
+    return;
+  }
   TRY
   HIPCHK(hipStreamSynchronize(r->stream));
   r->shard_rank = *rank; r->shard_world = *world;
@@ -1645,6 +1777,111 @@ void radtran_set_bin_shard(void *ptr, const int *rank, const int *world, char *e
   }
   HIPCHK(hipStreamSynchronize(r->stream));
   CATCH(err)
+}
+
+// ---- the library's own multi-GPU step ---------------------------------------
+// One process per GPU.  Each rank builds the same Radtran, then joins a communicator; from then on every
+// radiate() / TOA_fluxes() / radiate_resident() of the handle works on the rank's own spectral bins and ends
+// with one ncclAllReduce (sum, f64, 4 (nz+1) + 1 values) on the handle's stream, so that wrk_ir%fup_n ...
+// f_total, ISR and OLR are those of the whole spectrum on every rank (per-bin spectra stay sharded: zeros
+// outside the rank's bins).  The reduction being distributed: clima_radtran_radiate.f90:184-192.
+
+void radtran_set_device(const int *device, char *err) {
+  clear_err(err);
+  TRY
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (*device < 0 || *device >= n) throw HipFail{"radtran_set_device: no such HIP device"};
+  HIPCHK(hipSetDevice(*device));
+  CATCH(err)
+}
+
+void radtran_comm_unique_id(char *id, char *err) {
+  clear_err(err);
+  TRY
+  static_assert(sizeof(ncclUniqueId) == CLIMA_COMM_ID_BYTES, "CLIMA_COMM_ID_BYTES is RCCL's NCCL_UNIQUE_ID_BYTES");
+  ncclUniqueId u;
+  NCCLCHK(ncclGetUniqueId(&u));
+  std::memcpy(id, &u, sizeof(u));
+  CATCH(err)
+}
+
+static void comm_attach(Radtran *r, int nranks, int rank, const char *id) {
+  if (r->comm) throw HipFail{"this handle already has a communicator"};
+  HIPCHK(hipSetDevice(r->device));
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  NCCLCHK(ncclCommInitRank(&r->comm, nranks, u, rank));
+  r->comm_n = nranks; r->comm_rank = rank;
+}
+
+void radtran_comm_init_rank(void *ptr, const int *nranks, const int *rank, const char *id, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  if (*nranks < 1 || *rank < 0 || *rank >= *nranks) { set_err(err, "invalid communicator (rank, nranks)"); return; }
+  TRY
+  comm_attach(r, *nranks, *rank, id);
+  CATCH(err)
+  if (err && err[0]) return;
+  radtran_set_bin_shard(ptr, rank, nranks, err);
+}
+
+// The same for hosts without a message layer of their own (a plain Fortran program started once per GPU): rank 0
+// writes the id to `path` (created atomically; removed again once every rank has joined), the others wait for it.
+// `path` must be new for every job.
+void radtran_comm_init_file(void *ptr, const int *nranks, const int *rank, const char *path, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  if (*nranks < 1 || *rank < 0 || *rank >= *nranks) { set_err(err, "invalid communicator (rank, nranks)"); return; }
+  if (!path || !path[0]) { set_err(err, "radtran_comm_init_file: empty path"); return; }
+  TRY
+  char id[CLIMA_COMM_ID_BYTES];
+  const std::string file(path), tmp = file + ".tmp";
+  if (*rank == 0) {
+    ncclUniqueId u;
+    NCCLCHK(ncclGetUniqueId(&u));
+    std::memcpy(id, &u, sizeof(u));
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0 || std::rename(tmp.c_str(), file.c_str()) != 0)
+      throw HipFail{"radtran_comm_init_file: cannot write " + file};
+  } else {
+    bool got = false;
+    for (int tries = 0; tries < 6000 && !got; tries++) {   // up to ~120 s
+      struct stat st;
+      if (stat(file.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(id)) {
+        FILE *f = std::fopen(file.c_str(), "rb");
+        got = f && std::fread(id, 1, sizeof(id), f) == sizeof(id);
+        if (f) std::fclose(f);
+      }
+      if (!got) usleep(20000);
+    }
+    if (!got) throw HipFail{"radtran_comm_init_file: rank 0 did not publish " + file};
+  }
+  comm_attach(r, *nranks, *rank, id);   // collective: returns once every rank has joined
+  if (*rank == 0) (void)std::remove(file.c_str());
+  CATCH(err)
+  if (err && err[0]) return;
+  radtran_set_bin_shard(ptr, rank, nranks, err);
+}
+
+void radtran_comm_get(void *ptr, int *nranks, int *rank, int *reduces) {
+  Radtran *r = as_rad(ptr);
+  *nranks = (r && r->comm) ? r->comm_n : 0;
+  *rank = (r && r->comm) ? r->comm_rank : 0;
+  if (reduces) *reduces = r ? (int)std::min<long>(r->comm_reduces, 2147483647L) : 0;
+}
+
+void radtran_comm_destroy(void *ptr) {
+  Radtran *r = as_rad(ptr);
+  if (!r || !r->comm) return;
+  (void)hipStreamSynchronize(r->stream);
+  (void)ncclCommDestroy(r->comm);
+  r->comm = nullptr; r->comm_n = 1; r->comm_rank = 0;
+  const int zero = 0, one = 1;
+  char e[CLIMA_ERR_LEN + 1];
+  radtran_set_bin_shard(ptr, &zero, &one, e);   // back to the whole spectrum
 }
 
 void radtran_bin_shard_get(void *ptr, int *op_lo, int *op_n, int *ir_lo, int *ir_n, int *sol_lo, int *sol_n) {
@@ -1795,9 +2032,9 @@ void radtran_opr_get(void *ptr, double *tau, double *w0, double *g, double *tau_
   GUARD(r, ptr, err);
   if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
   TRY
+  settle(r);       // (a repaired hand-off recomputes the optical properties)
   ensure_w0(r);
   HIPCHK(hipStreamSynchronize(r->stream));
-  resolve_events(r);
   if (tau) HIPCHK(hipMemcpy(tau, r->d_tau.p, r->d_tau.n * sizeof(double), hipMemcpyDeviceToHost));
   if (w0) HIPCHK(hipMemcpy(w0, r->d_w0.p, r->d_w0.n * sizeof(double), hipMemcpyDeviceToHost));
   if (g) HIPCHK(hipMemcpy(g, r->d_g.p, r->d_g.n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1862,8 +2099,9 @@ void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, d
 // channels, `ng` g-points carrying the same tau/w0 with weights wbin (sum 1), one zenith angle u0 of
 // weight 1, unit stellar flux and unit factors, so the kernels' weighted sums reproduce the solver's
 // own outputs.  form: 0 wave-per-column kernel (k_twostream_w<slots>), 1 workgroup-per-bin kernel
-// (k_twostream), 2 the two-stream part of the fused grid (k_fused, slots 2..4, ng = 8), 4 the same in the
-// half-wave form (two g-point columns per wave, slots = ceil(nz/32) = 3..7),
+// (k_twostream), 2 the two-stream part of the fused grid (k_fused, whole-wave form, slots 2..8, ng = 8), 4 the
+// same in the half-wave form (two g-point columns per wave, slots = ceil(nz/32) = 3..7), 5 the same in the
+// paired form (every layer 2m+1 a copy of layer 2m: even nz, slots 2, 4, 6, 8; the caller passes such a column),
 // 3 batched shared-opacity IR kernel (k_twostream_ir_batch<slots>, IR outputs only).
 // slots = layer slots per lane (>= ceil(nz/64)).  Outputs are TOA-first like the solver's.
 void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, const int *slots, const double *tau,
@@ -1912,9 +2150,13 @@ void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, cons
   size_t lds = 0;
   if (*form == 0) ok = launch_twostream_w(ts, nullptr, &lds, false);
   else if (*form == 1) ok = launch_twostream(ts, nullptr, &lds);
-  else if (*form == 2 || *form == 4) {   // 4: the half-wave form (two g-point columns per wave)
+  else if (*form == 2 || *form == 4 || *form == 5) {   // 4: the half-wave form (two g-point columns per wave), 5: the paired form
+    if (*form == 5)
+      for (int i = 0; i + 1 < nz; i += 2)
+        if (tau[i] != tau[i + 1] || w0[i] != w0[i + 1] || g[i] != g[i + 1])
+          throw HipFail{"clima_test_two_stream: form 5 needs a column of pairwise identical layers"};
     d_qm.upload(std::vector<int>{nz});  // the column's source-layer count
-    ok = launch_fused_twostream_only(ts, *slots, d_qm.p, nullptr, *form == 4);
+    ok = launch_fused_twostream_only(ts, *slots, d_qm.p, nullptr, *form == 4, *form == 5);
   }
   else if (*form == 3) { ts.b_T = 0; ts.b_Ts = 0; ts.b_out = 0; ok = launch_twostream_ir_batch(ts, 1, nullptr); }
   HIPCHK(hipGetLastError());
@@ -2013,7 +2255,10 @@ void radtran_f_total_get(void *ptr, const int *dim1, double *arr) {
   try {
     fetch_small(r);
     for (int i = 0; i < *dim1 && i < r->nz + 1; i++) arr[i] = r->h_small[4 * (r->nz + 1) + i];
+  } catch (const HipFail &f) {
+    defer_err(r, f.msg);   // no `err` here (clima/fortran/Radtran.f90 getters have none): radtran_synchronize reports it
   } catch (...) {
+    defer_err(r, "radtran_f_total_get failed");
   }
 }
 void radtran_photons_sol_get_size(void *ptr, int *dim1) { Radtran *r = as_rad(ptr); *dim1 = r ? (int)r->photons_sol.size() : 0; }
@@ -2033,7 +2278,9 @@ static int ch_nw(WrkObj *w) { return w->which ? w->parent->sol.nw : w->parent->i
   }                                                                                       \
   void climaradtranwrk_##name##_get(void *ptr, const int *dim1, const int *dim2, double *arr) { \
     WrkObj *w = reinterpret_cast<WrkObj *>(ptr);                                          \
-    try { get2d(w, w->field, *dim1, *dim2, arr); } catch (...) {}                          \
+    try { get2d(w, w->field, *dim1, *dim2, arr); }                                        \
+    catch (const HipFail &f) { defer_err(w->parent, f.msg); }                             \
+    catch (...) { defer_err(w->parent, "climaradtranwrk getter failed"); }                \
   }
 WRK2D(fup_a, fup_a, 1)
 WRK2D(fdn_a, fdn_a, 1)
@@ -2052,7 +2299,8 @@ WRK2D(tau_band, tau_band, 0)
       const int nl = r->nz + 1;                                                           \
       const int a = (w->which ? 2 : 0) + ((up) ? 0 : 1);                                  \
       for (int i = 0; i < *dim1 && i < nl; i++) arr[i] = r->h_small[a * nl + i];          \
-    } catch (...) {}                                                                      \
+    } catch (const HipFail &f) { defer_err(r, f.msg);                                     \
+    } catch (...) { defer_err(r, "climaradtranwrk getter failed"); }                      \
   }
 WRK1D(fup_n, 1)
 WRK1D(fdn_n, 0)

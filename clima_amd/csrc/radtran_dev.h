@@ -236,6 +236,12 @@ struct IntegrateParams {
   double *f_total;
   double *partial;                         // [4][nchunk][nz+1] chunk sums
   int nchunk;
+  // handles with a communicator (radtran_comm_init_rank): one more word rides on the all-reduce behind the four
+  // level rows -- 1 when this rank's fused hand-off timed out in the opacity pass `id_opr`, + 1024 when it did in
+  // the pass of the last solar computation `id_sol` -- so that EVERY rank learns it and repeats the step unfused
+  double *timeout_out;
+  const int *timeout_flag;
+  int id_opr, id_sol;
 };
 
 struct BatchIntegrateParams {
@@ -262,7 +268,7 @@ int fused_tiles(const OpacityParams &op);   // opacity tiles per column (size of
 bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, hipStream_t s);
 // test hook: the two-stream blocks of the fused grid alone (no opacity blocks), on opacities already in HBM
 // (meta_nsrc: a device int, any value >= 1)
-bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s, bool half = false);
+bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s, bool half = false, bool paired = false);
 int twostream_w_groups(int ng);
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
 void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t s);

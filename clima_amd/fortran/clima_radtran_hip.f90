@@ -21,10 +21,12 @@ module clima_radtran_hip
   private
 
   public :: Radtran, ClimaRadtranWrk, RTChannel, dp
+  public :: radtran_set_device, radtran_comm_unique_id, comm_id_bytes
   public :: CIAXsection, RayleighXsection, AbsorptionXsection, PhotolysisXsection
 
   integer, parameter :: dp = c_double
   integer, parameter :: err_len = 1024
+  integer, parameter :: comm_id_bytes = 128   !! CLIMA_COMM_ID_BYTES of include/clima_radtran_hip.h
   ! enum of src/radtran/clima_radtran_types.f90:40-42
   integer, parameter :: CIAXsection = 0, RayleighXsection = 1, AbsorptionXsection = 2, PhotolysisXsection = 3
 
@@ -81,6 +83,13 @@ module clima_radtran_hip
     procedure :: set_custom_optical_properties => Radtran_set_custom_optical_properties
     procedure :: unset_custom_optical_properties => Radtran_unset_custom_optical_properties
     procedure :: destroy => Radtran_destroy
+    !> The library's own multi-GPU step (one process per GPU, include/clima_radtran_hip.h radtran_comm_*):
+    !> after `comm_init` / `comm_init_file`, `radiate` and `TOA_fluxes` work on this rank's spectral bins
+    !> and end with one RCCL all-reduce of the level fluxes; `wrk_ir%fup_n` ... `f_total` are the whole
+    !> spectrum's on every rank (the sum over bins of src/radtran/clima_radtran_radiate.f90:184-192).
+    procedure :: comm_init => Radtran_comm_init
+    procedure :: comm_init_file => Radtran_comm_init_file
+    procedure :: comm_destroy => Radtran_comm_destroy
   end type
 
   interface
@@ -322,6 +331,28 @@ module clima_radtran_hip
       import; type(c_ptr), value :: ptr
       integer(c_int), intent(in) :: dim1
       real(c_double), intent(out) :: arr(*)
+    end subroutine
+    subroutine c_radtran_set_device(device, err) bind(c, name="radtran_set_device")
+      import; integer(c_int), intent(in) :: device
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_comm_unique_id(id, err) bind(c, name="radtran_comm_unique_id")
+      import; character(c_char), intent(out) :: id(*), err(*)
+    end subroutine
+    subroutine c_radtran_comm_init_rank(ptr, nranks, rank, id, err) bind(c, name="radtran_comm_init_rank")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: nranks, rank
+      character(c_char), intent(in) :: id(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_comm_init_file(ptr, nranks, rank, path, err) bind(c, name="radtran_comm_init_file")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: nranks, rank
+      character(c_char), intent(in) :: path(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_comm_destroy(ptr) bind(c, name="radtran_comm_destroy")
+      import; type(c_ptr), value :: ptr
     end subroutine
     subroutine c_climaradtranwrk_fdn_n_get(ptr, dim1, arr) bind(c, name="climaradtranwrk_fdn_n_get")
       import; type(c_ptr), value :: ptr
@@ -751,6 +782,59 @@ contains
     class(Radtran), intent(inout) :: self
     if (c_associated(self%handle)) call c_deallocate_radtran(self%handle)
     self%handle = c_null_ptr
+  end subroutine
+
+  !> select this process's GPU (before `finish`)
+  subroutine radtran_set_device(device, err)
+    integer, intent(in) :: device
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    call c_radtran_set_device(int(device, c_int), err_c)
+    call take_err(err_c, err)
+  end subroutine
+
+  !> rank 0: a fresh communicator id, to be handed to every rank (MPI_Bcast of comm_id_bytes characters, ...)
+  subroutine radtran_comm_unique_id(id, err)
+    character(c_char), intent(out) :: id(comm_id_bytes)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    call c_radtran_comm_unique_id(id, err_c)
+    call take_err(err_c, err)
+  end subroutine
+
+  !> collective over the `nranks` processes (rank 0-based); restricts the handle to its share of the bins
+  subroutine Radtran_comm_init(self, nranks, rank, id, err)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: nranks, rank
+    character(c_char), intent(in) :: id(comm_id_bytes)
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    call c_radtran_comm_init_rank(self%handle, int(nranks, c_int), int(rank, c_int), id, err_c)
+    call take_err(err_c, err)
+  end subroutine
+
+  !> the same with the id exchanged through a file that rank 0 creates (`path` new for every job)
+  subroutine Radtran_comm_init_file(self, nranks, rank, path, err)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: nranks, rank
+    character(*), intent(in) :: path
+    character(:), allocatable, intent(out) :: err
+    character(c_char) :: err_c(err_len+1)
+    character(c_char), allocatable :: path_c(:)
+    integer :: i, n
+    n = len_trim(path)
+    allocate(path_c(n+1))
+    do i = 1, n
+      path_c(i) = path(i:i)
+    enddo
+    path_c(n+1) = c_null_char
+    call c_radtran_comm_init_file(self%handle, int(nranks, c_int), int(rank, c_int), path_c, err_c)
+    call take_err(err_c, err)
+  end subroutine
+
+  subroutine Radtran_comm_destroy(self)
+    class(Radtran), intent(inout) :: self
+    if (c_associated(self%handle)) call c_radtran_comm_destroy(self%handle)
   end subroutine
 
 end module

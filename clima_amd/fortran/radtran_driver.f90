@@ -3,9 +3,18 @@
 !> The tables and the column come from a binary case file written by
 !> clima_amd/fortran_case.py (the reference reads YAML/HDF5/atmosphere.txt here; those
 !> loaders are outside the hot path).  Usage: radtran_driver case.bin result.txt
+!>
+!> Multi-GPU mode (the library's own RCCL step): start the program once per GPU with
+!>     radtran_driver case.bin result.txt <rank> <nranks> <id-file> [<device>]
+!> (rank 0-based; <id-file> a path that is new for this job; <device> defaults to <rank>).  Every rank builds
+!> the same Radtran, joins the communicator (`rad%comm_init_file`) and then runs exactly the same calls: each
+!> `rad%radiate` works on the rank's share of the spectral bins and ends with one all-reduce of the level
+!> fluxes, so the level fluxes, f_total, ISR and OLR every rank writes are those of the whole spectrum.  Per-bin
+!> spectra stay sharded, and the batched entry points are not available on a sharded handle: in this mode the
+!> program stops after the two radiate calls.
 program radtran_driver
   use iso_fortran_env, only: int32, output_unit
-  use clima_radtran_hip, only: Radtran, dp
+  use clima_radtran_hip, only: Radtran, dp, radtran_set_device
   implicit none
   type(Radtran) :: rad
   character(:), allocatable :: err
@@ -18,9 +27,23 @@ program radtran_driver
   real(dp), allocatable :: ir_wavl(:), sol_wavl(:), photons(:)
   real(dp), allocatable :: T(:), P(:), densities(:,:), dz(:), pdensities(:,:), radii(:,:)
   integer :: i, u
+  integer :: my_rank, n_ranks, my_device
+  character(1024) :: arg, id_file
+  logical :: sharded
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
+  sharded = command_argument_count() >= 5
+  if (sharded) then
+    call get_command_argument(3, arg); read(arg, *) my_rank
+    call get_command_argument(4, arg); read(arg, *) n_ranks
+    call get_command_argument(5, id_file)
+    my_device = my_rank
+    if (command_argument_count() >= 6) then
+      call get_command_argument(6, arg); read(arg, *) my_device
+    endif
+    call radtran_set_device(my_device, err); call check()
+  endif
   open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
   read(u) nz, nsp, np, nw, nzen
   read(u) albedo
@@ -68,6 +91,9 @@ program radtran_driver
   allocate(photons(n_sol-1)); read(u) photons
   call rad%set_photons_sol(photons, err); call check()
   call rad%finish(nzen, albedo, err); call check()
+  if (sharded) then
+    call rad%comm_init_file(n_ranks, my_rank, trim(id_file), err); call check()
+  endif
 
   allocate(T(nz), P(nz), densities(nz,nsp), dz(nz), pdensities(nz,np), radii(nz,np))
   read(u) T_surface; read(u) T; read(u) P; read(u) densities; read(u) dz
@@ -103,6 +129,12 @@ program radtran_driver
   write(u,'(es26.17e3)') rad%f_total
   write(u,'(es26.17e3)') rad%wrk_ir%fup_a(nz+1,:)   ! tests/test_radtran.f90:77
   write(u,'(es26.17e3)') rad%wrk_sol%fup_a(nz+1,:)  ! :79
+  if (sharded) then
+    close(u)
+    call rad%comm_destroy()
+    call rad%destroy()
+    stop
+  endif
 
   ! the same pattern batched: three temperature columns (base, surface +1 K, layer 1 +1 K)
   block

@@ -55,6 +55,12 @@ SIGNATURES = {
     "radtran_set_bin_shard": [_vp, _ip, _ip, _err],
     "radtran_bin_shard_get": [_vp, _ip, _ip, _ip, _ip, _ip, _ip],
     "radtran_finish_reduced": [_vp, _err],
+    "radtran_set_device": [_ip, _err],
+    "radtran_comm_unique_id": [_err, _err],
+    "radtran_comm_init_rank": [_vp, _ip, _ip, _err, _err],
+    "radtran_comm_init_file": [_vp, _ip, _ip, _err, _err],
+    "radtran_comm_get": [_vp, _ip, _ip, _ip],
+    "radtran_comm_destroy": [_vp],
     "radtran_stream_get": [_vp, _vpp],
     "radtran_profile_set": [_vp, _ip],
     "radtran_kernel_time_get": [_vp, _ip, _dp, _ip, _err],
@@ -63,6 +69,9 @@ SIGNATURES = {
     "radtran_algorithmic_bytes": [_vp, _dp, _dp, _dp, _dp, _err],
     "radtran_algorithmic_nodes": [_vp, _dp, _dp, _dp, _dp, _err],
     "radtran_opr_get": [_vp, _dp, _dp, _dp, _dp, _err],
+    "clima_bench_toa_fluxes": [_vp, _ip, _dp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _ip, _ip,
+                               _dp, _dp, _dp, _dp, _err],
+    "clima_bench_resident_sync": [_vp, _ip, _dp, _err],
     "clima_test_device_exp": [_ip, _dp, _dp, _err],
     "clima_test_device_exp_table": [_ip, _ip, _dp, _dp, _err],
     "clima_test_device_rcp": [_ip, _dp, _dp, _err],

@@ -7,6 +7,7 @@ The reference's Python layer reaches `Radtran%radiate` only through `AdiabatClim
 HDF5/YAML loaders are outside the hot path (SURVEY.md 8(f) "next #1").
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -216,6 +217,24 @@ class Radtran:
         self._check()
         return isr.value, olr.value
 
+    def bench_toa_fluxes(self, n, T_surface, T, P, densities, dz, pdensities=None, radii=None):
+        """`n` synchronous TOA_fluxes calls timed one by one INSIDE the library (us per call, numpy array):
+        the drop-in call as a Fortran / C host sees it, without the ctypes layer's own cost."""
+        keep, a = self._column_args(T, P, densities, dz, pdensities, radii)
+        us = np.zeros(int(n))
+        isr, olr = C.c_double(), C.c_double()
+        self._L.clima_bench_toa_fluxes(self._ptr, _i(n), _f(T_surface), *a, _d(us), C.byref(isr), C.byref(olr), self._err)
+        del keep
+        self._check()
+        return us
+
+    def bench_resident_sync(self, n):
+        """`n` times radiate_resident + synchronize, timed one by one inside the library (us per call)."""
+        us = np.zeros(int(n))
+        self._L.clima_bench_resident_sync(self._ptr, _i(n), _d(us), self._err)
+        self._check()
+        return us
+
     def apply_radiation_enhancement(self, rad_enhancement):
         self._L.radtran_apply_radiation_enhancement(self._ptr, _f(rad_enhancement))
 
@@ -317,6 +336,48 @@ class Radtran:
     def set_bin_shard(self, rank, world):
         self._L.radtran_set_bin_shard(self._ptr, _i(rank), _i(world), self._err)
         self._check()
+
+    # ---- the library's own multi-GPU step (include/clima_radtran_hip.h, radtran_comm_*): one process per GPU;
+    # after comm_init_* every radiate / TOA_fluxes / radiate_resident of this handle works on the rank's bins and
+    # ends with one RCCL all-reduce of the level fluxes on the handle's stream
+    COMM_ID_BYTES = 128
+
+    @staticmethod
+    def set_device(device):
+        L = _lib.load()
+        err = C.create_string_buffer(_lib.ERR_LEN + 1)
+        L.radtran_set_device(_i(device), err)
+        if err.value:
+            raise ClimaException(err.value.decode())
+
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: a fresh communicator id (bytes) to hand to every rank."""
+        L = _lib.load()
+        err = C.create_string_buffer(_lib.ERR_LEN + 1)
+        buf = C.create_string_buffer(Radtran.COMM_ID_BYTES)
+        L.radtran_comm_unique_id(buf, err)
+        if err.value:
+            raise ClimaException(err.value.decode())
+        return buf.raw
+
+    def comm_init_rank(self, nranks, rank, comm_id):
+        assert len(comm_id) == self.COMM_ID_BYTES
+        self._L.radtran_comm_init_rank(self._ptr, _i(nranks), _i(rank), C.create_string_buffer(bytes(comm_id), self.COMM_ID_BYTES), self._err)
+        self._check()
+
+    def comm_init_file(self, nranks, rank, path):
+        self._L.radtran_comm_init_file(self._ptr, _i(nranks), _i(rank), os.fsencode(path), self._err)
+        self._check()
+
+    def comm(self):
+        """(nranks, rank, all-reduces enqueued so far); nranks 0 without a communicator"""
+        n, r, k = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._L.radtran_comm_get(self._ptr, C.byref(n), C.byref(r), C.byref(k))
+        return n.value, r.value, k.value
+
+    def comm_destroy(self):
+        self._L.radtran_comm_destroy(self._ptr)
 
     def bin_shard(self):
         v = [C.c_int() for _ in range(6)]

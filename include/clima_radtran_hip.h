@@ -140,6 +140,30 @@ void radtran_bin_shard_get(void *ptr, int *op_lo, int *op_n, int *ir_lo, int *ir
 /* after an external all-reduce of the flux buffer: the level rows have changed; f_total is formed
  * from them when the results are next read */
 void radtran_finish_reduced(void *ptr, char *err);
+
+/* ---- The multi-GPU step owned by the library (bins shard over the GPUs of a node, one RCCL
+ * all-reduce of the per-layer integrated fluxes).  One process per GPU; every rank constructs the same Radtran
+ * (after radtran_set_device) and joins a communicator.  From then on radtran_radiate_wrapper /
+ * radtran_toa_fluxes_wrapper / radtran_radiate_resident work on the rank's own spectral bins and end with ONE
+ * ncclAllReduce (sum, f64, 4 (nz+1) + 1 values) enqueued on the handle's stream: the level fluxes, f_total, ISR
+ * and OLR every rank reads are those of the whole spectrum; per-bin spectra stay sharded (zeros outside the
+ * rank's bins).  What is distributed is the sum over bins of src/radtran/clima_radtran_radiate.f90:184-192 and
+ * f_total of clima_radtran.f90:287, 316.  A fused hand-off timeout on any rank is repeated by all of them
+ * (the flag travels on the same all-reduce), never reported as an error. */
+#define CLIMA_COMM_ID_BYTES 128   /* = NCCL_UNIQUE_ID_BYTES */
+/* select the HIP device of this process (before radtran_create_end) */
+void radtran_set_device(const int *device, char *err);
+/* rank 0: a fresh communicator id, to be handed to every rank by the caller's own means (MPI_Bcast, a file ...) */
+void radtran_comm_unique_id(char *id /* [CLIMA_COMM_ID_BYTES] */, char *err);
+/* collective over the nranks processes; also restricts the handle to the bins of shard (rank, nranks) */
+void radtran_comm_init_rank(void *ptr, const int *nranks, const int *rank, const char *id, char *err);
+/* the same with the id exchanged through a file that rank 0 creates (hosts without a message layer);
+ * `path` (NUL-terminated) must be new for every job */
+void radtran_comm_init_file(void *ptr, const int *nranks, const int *rank, const char *path, char *err);
+/* nranks (0: no communicator), rank, all-reduces enqueued so far */
+void radtran_comm_get(void *ptr, int *nranks, int *rank, int *reduces);
+/* leave the communicator; the handle works on the whole spectrum again */
+void radtran_comm_destroy(void *ptr);
 /* Column batch (BASELINE.json config 4): ncol independent Radtran%TOA_fluxes calls
  * (src/radtran/clima_radtran.f90:320-342), moved to HBM in one copy and enqueued back to back.
  * Inputs as radtran_toa_fluxes_wrapper with the column as the last dimension: T, P, dz (nz, ncol),
@@ -207,6 +231,17 @@ void radtran_algorithmic_bytes(void *ptr, double *bytes_tables_distinct, double 
  * k-tables, and the table's nP*nT) and N_T (the same for the 1-D temperature tables) */
 void radtran_algorithmic_nodes(void *ptr, double *n_pt, double *n_pt_full, double *n_t, double *n_t_full, char *err);
 
+/* bench hooks: n calls timed one by one with the host's steady clock INSIDE the library (us[n]) -- what a
+ * Fortran / C caller sees, without a foreign-function layer's own cost.  clima_bench_toa_fluxes: the synchronous
+ * drop-in call radtran_toa_fluxes_wrapper (arguments as there; compute_solar = compute_opacity = 1);
+ * clima_bench_resident_sync: radtran_radiate_resident + radtran_synchronize per call (column already in HBM). */
+void clima_bench_toa_fluxes(void *ptr, const int *n, const double *T_surface, const int *dim_T, const double *T,
+                            const int *dim_P, const double *P, const int *dim1_d, const int *dim2_d,
+                            const double *densities, const int *dim_dz, const double *dz, const int *has_particles,
+                            const int *dim1_p, const int *dim2_p, const double *pdensities, const int *dim1_r,
+                            const int *dim2_r, const double *radii, double *us, double *ISR, double *OLR, char *err);
+void clima_bench_resident_sync(void *ptr, const int *n, double *us, char *err);
+
 /* test hook: y[i] = the kernels' device exp(x[i]) (used where the reference calls exp) */
 void clima_test_device_exp(const int *n, const double *x, double *y, char *err);
 void clima_test_device_exp_table(const int *n, const int *base10, const double *x, double *y, char *err);
@@ -222,7 +257,10 @@ void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, d
  * two_stream_ir / two_stream_solar (src/radtran/clima_radtran_twostream.f90:10-295).  ir_par =
  * {emissivity, has_hard_surface, ir_tau_min}, sol_par = {u0, Rsfc}; ng g-points of weights wbin (sum
  * 1) carry the same column.  form 0: k_twostream_w<slots>, 1: k_twostream, 2: two-stream part of
- * k_fused (slots 2..4, ng 8), 3: k_twostream_ir_batch<slots> (IR only).  Outputs (nz+1) TOA-first. */
+ * k_fused in its whole-wave form (slots 2..8, ng 8), 4: the same in the half-wave form (two g-point columns
+ * per wave, slots = ceil(nz/32) = 3..7), 5: the same in the paired form (a column of pairwise identical
+ * layers -- AdiabatClimate's doubled radiative grid -- even nz, slots 2, 4, 6, 8),
+ * 3: k_twostream_ir_batch<slots> (IR only).  Outputs (nz+1) TOA-first. */
 void clima_test_two_stream(const int *nz, const int *ng, const int *form, const int *slots, const double *tau,
                            const double *w0, const double *g, const double *bplanck, const double *ir_par,
                            const double *sol_par, const double *wbin, double *ir_fup, double *ir_fdn,

@@ -14,6 +14,8 @@ values are random over four decades from level to level, which makes the IR sour
 (B_{i+1}-B_i)/tau of thin layers deliberately ill-conditioned.
 Cases 36-67: smooth Planck profiles and pressure-like optical depths (the shape of a real call) at
 nz = 1 ... 512, including every chunk edge of the 64-lane decomposition.
+Cases 68-89: the same kind of column with pairwise identical layers (the doubled radiative grid of
+AdiabatClimate), nz = 2 ... 512 even, for the paired kernel instantiations.
 """
 import os
 import sys
@@ -82,6 +84,36 @@ def main():
             fup, fdn = O.ref_two_stream_ir(tau, w0, g, em, hs, 1e-6, bp)
             u0 = [0.6, 0.25][variant]
             rs = [0.2, 0.6][variant]
+            am, sr, sfup, sfdn = O.ref_two_stream_solar(tau, w0, g, u0, rs)
+            k = "c%02d_" % n
+            out.update({k + "tau": tau, k + "w0": w0, k + "g": g, k + "bplanck": bp,
+                        k + "ir_par": np.array([em, float(hs), 1e-6]), k + "ir_fup": fup, k + "ir_fdn": fdn,
+                        k + "sol_par": np.array([u0, rs]), k + "sol_amean": am, k + "sol_sr": np.array([sr]),
+                        k + "sol_fup": sfup, k + "sol_fdn": sfdn})
+            n += 1
+    # ---- cases 68...: columns of pairwise identical layers (tau, w0, g of layer 2m+1 = those of layer 2m; the
+    # levels' Planck values stay their own) -- what AdiabatClimate's doubled radiative grid hands to the solver
+    # (src/adiabat/clima_adiabat.f90:729-773), and what the PAIRED instantiations of the fused grid's two-stream
+    # part are selected for.  Heights reach every paired slot count (2, 4, 6, 8 = 2 ceil((nz/2)/64)) and its edges.
+    out["paired_first"] = np.array([n])
+    rng3 = np.random.default_rng(20261006)
+    for nz in (2, 66, 102, 128, 130, 202, 256, 258, 384, 402, 512):
+        for variant in range(2):
+            lev = np.linspace(0.0, 1.0, nz + 1)                      # TOA -> ground
+            T = 175.0 + 120.0 * lev ** (1.0 if variant == 0 else 2.0) + rng3.uniform(-1.0, 1.0, nz + 1)
+            nu = [3.0e13, 5.0e13][variant]
+            bp = 1.0e3 * ((2.0 * h * nu ** 3) / cl ** 2) / (np.exp((h * nu) / (kb * T)) - 1.0)
+            nh = nz // 2
+            midh = (np.arange(nh) + 0.5) / nh
+            tau_h = (10.0 ** rng3.uniform(-3, 1.5)) * (midh ** 2 + 1e-4) / nz * 40.0 * 10 ** rng3.uniform(-0.3, 0.3, nh)
+            w0_h = rng3.uniform(0.0, 0.9 if variant == 0 else 0.3, nh)
+            g_h = rng3.uniform(0.0, 0.85, nh)
+            tau, w0, g = np.repeat(tau_h, 2), np.repeat(w0_h, 2), np.repeat(g_h, 2)
+            hs = variant == 0
+            em = 1.0 if variant == 0 else 0.85
+            fup, fdn = O.ref_two_stream_ir(tau, w0, g, em, hs, 1e-6, bp)
+            u0 = [0.55, 0.3][variant]
+            rs = [0.25, 0.5][variant]
             am, sr, sfup, sfdn = O.ref_two_stream_solar(tau, w0, g, u0, rs)
             k = "c%02d_" % n
             out.update({k + "tau": tau, k + "w0": w0, k + "g": g, k + "bplanck": bp,
