@@ -2759,26 +2759,28 @@ void launch_test_wscan(const double *a, const double *b, double *out, int nwaves
 // with beta, gamma, B, sb and the reflectances rho fixed by the opacities.
 // One block = the (up to) 8 g-point waves of one bin; it loops over its share of the columns.
 // ------------------------------------------------------------------------------------
-constexpr int IRB_WAVES = 8;   // g-point waves per block: the kernel covers ng <= 8
 constexpr int IRB_TILE = 8;    // columns whose Planck values sit in LDS together
 // (working on two columns at once, to interleave their dependent chains, spilled ~100 more
 // registers and measured slower: 13.5 vs 10.0 us per column)
-
-template <int L>
-__global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStreamParams p, int ncol, int cols_per_block) {
+//
+// NW = g-point waves per block.  Up to 4 layer slots per lane (nz <= 256) a block is 8 waves -- all g-points of
+// the usual k-distribution at once, two waves per SIMD, 256 registers each.  5-8 slots (257-512 layers:
+// AdiabatClimate's doubled radiative grid at nz = 200 is 402) need ~300 registers per lane: those instances are
+// blocks of FOUR waves, one wave per SIMD, which gives the register allocator the SIMD's whole file (256 VGPRs +
+// 256 AGPRs as spill space: a register-to-register move where scratch would be an L2 round trip).  The g-points
+// are taken in groups of NW, one group after the other, and a group adds its weighted level fluxes onto what the
+// groups before it left in the output (the same thread wrote it): the sum over the g-points keeps the order
+// ((f0 + f1) + f2) + ... whatever NW is, so both forms agree to rounding (hipcc contracts a few products differently in the two instances) -- and any
+// g-point count is covered.
+template <int L, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_twostream_ir_batch(TwoStreamParams p, int ncol, int cols_per_block) {
   extern __shared__ __align__(16) double lds[];
   const int nz = p.nz, ng = p.ng, nl = nz + 1;
   double *sB = lds;                          // [IRB_TILE][nl] Planck, TOA-first levels
-  double *sF0 = lds + (size_t)IRB_TILE * nl;  // [2 columns][2][IRB_WAVES][nl] weighted level fluxes
+  double *sF0 = lds + (size_t)IRB_TILE * nl;  // [2 columns][2][NW][nl + 1] weighted level fluxes (+ a dump entry per row)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ll = p.ir_lo + (int)blockIdx.x;
   const int l = p.ir_start + ll;
-  const bool col_on = wave < ng;
-  const int cg = col_on ? wave : ng - 1;
-  const double wcol = col_on ? p.wbin[cg] : 0.0;
-  const double *tauL = p.tau + ((size_t)l * ng + cg) * nz;
-  const double *w0L = p.w0 + ((size_t)l * ng + cg) * nz;
-  const double *gL = p.g + (size_t)l * nz;
   // slots as in twostream_p_body: L per lane, a short chunk padded from the top with
   // zero-thickness layers, so that nothing below branches on the chunk's length
   const int a = (lane * nz) >> 6, b = ((lane + 1) * nz) >> 6, pad = L - (b - a);
@@ -2787,6 +2789,17 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
   const bool hard = p.has_hard_surface != 0;
   const double emis = hard ? p.emissivity[ll] : 0.0;
   const double Rsfc = hard ? 1.0 - emis : 0.0;  // twostream.f90:186-190
+  const int c_begin = (int)blockIdx.z * cols_per_block;
+  const int c_end = min(ncol, c_begin + cols_per_block);
+
+  // (the 8-wave form covers ng <= 8 in one group: written as a loop it cost the 4-slot instance 28 scratch accesses)
+  for (int g0 = 0; g0 < (NW == 8 ? 1 : ng); g0 += NW) {
+  const bool col_on = g0 + wave < ng;
+  const int cg = col_on ? g0 + wave : ng - 1;
+  const double wcol = col_on ? p.wbin[cg] : 0.0;
+  const double *tauL = p.tau + ((size_t)l * ng + cg) * nz;
+  const double *w0L = p.w0 + ((size_t)l * ng + cg) * nz;
+  const double *gL = p.g + (size_t)l * nz;
 
   // ---- temperature-independent part -------------------------------------------------
   double G[L], X[L], itau[L], rq[L], tauv[L];
@@ -2877,18 +2890,23 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
   // Both scans run over DPP (wscan_*); the bottom-up one is a prefix scan of the lane-reversed
   // data.  Their per-step multipliers live in LDS, one slot per thread and step: they are read
   // once per column and would otherwise cost 28 VGPRs.
-  double *sStep = sF0 + (size_t)4 * IRB_WAVES * nl + threadIdx.x;  // [2 * WSCAN_STEPS][blockDim.x]
+  // (the four-wave form has the SIMD's whole register file: there they stay in registers)
+  constexpr bool STEP_REGS = NW == 4;
+  double *sStep = sF0 + (size_t)4 * NW * (nl + 1) + threadIdx.x;  // [2 * WSCAN_STEPS][blockDim.x]
+  double stA[WSCAN_STEPS], stB[WSCAN_STEPS];
   {
-    double st[WSCAN_STEPS];
     double dummy = 0.0, bq = wave_reverse(uU * mm);
-    wscan_build(dummy, bq, st);
-#pragma unroll
-    for (int k = 0; k < WSCAN_STEPS; k++) sStep[(size_t)k * blockDim.x] = st[k];
+    wscan_build(dummy, bq, stA);
     double sb = dD * (1.0 + dU * mm * rho);
     dummy = 0.0;
-    wscan_build(dummy, sb, st);
+    wscan_build(dummy, sb, stB);
+    if constexpr (!STEP_REGS) {
 #pragma unroll
-    for (int k = 0; k < WSCAN_STEPS; k++) sStep[(size_t)(WSCAN_STEPS + k) * blockDim.x] = st[k];
+      for (int k = 0; k < WSCAN_STEPS; k++) {
+        sStep[(size_t)k * blockDim.x] = stA[k];
+        sStep[(size_t)(WSCAN_STEPS + k) * blockDim.x] = stB[k];
+      }
+    }
   }
   const double kA = uU * mm * rho;   // A_q = uS + kA*dS
   const double kS = dU * mm;         // sa_q = dS + kS*(rho*dS + sig)
@@ -2898,8 +2916,6 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
   for (int s = 0; s <= L; s++) face[s] = a + max(s - pad, 0);
 
   // ---- the columns ---------------------------------------------------------------------
-  const int c_begin = (int)blockIdx.z * cols_per_block;
-  const int c_end = min(ncol, c_begin + cols_per_block);
   for (int c0 = c_begin; c0 < c_end; c0 += IRB_TILE) {
     const int nt = min(IRB_TILE, c_end - c0);
     __syncthreads();  // the previous tile's Planck values are no longer read
@@ -2963,69 +2979,77 @@ __global__ __launch_bounds__(64 * IRB_WAVES, 1) void k_twostream_ir_batch(TwoStr
       const double dS = empty ? 0.0 : dd[2 * L - 2] * eb3 + dd[2 * L - 1] * eb4 + cmbv[L - 1];
       // bottom-up: source seen from above each interface (prefix scan in lane-reversed order),
       // then top-down: diffuse flux entering each chunk from above
-      const double sgr = wscan_apply(wave_reverse(uS + kA * dS), [&](int k) { return sStep[(size_t)k * blockDim.x]; });
+      const double sgr = wscan_apply(wave_reverse(uS + kA * dS),
+                                     [&](int k) { return STEP_REGS ? stA[k] : sStep[(size_t)k * blockDim.x]; });
       const double sig = wave_reverse(wave_shr1(sgr));   // below chunk q: what chunk q+1 shows from above; 0 under the last
       const double sa = wscan_apply(dS + kS * (rho * dS + sig),
-                                    [&](int k) { return sStep[(size_t)(WSCAN_STEPS + k) * blockDim.x]; });
+                                    [&](int k) { return STEP_REGS ? stB[k] : sStep[(size_t)(WSCAN_STEPS + k) * blockDim.x]; });
       const double Din = wave_shr1(sa);
       const double Uin = mm * (rho * dS + sig + rho * dD * Din);
       // level fluxes (:288-293), g-point weight; consecutive columns alternate the two staging buffers
       const int buf = cj & 1;
-      double *sFu = sF0 + (size_t)buf * 2 * IRB_WAVES * nl + (size_t)(0 * IRB_WAVES + wave) * nl;
-      double *sFd = sF0 + (size_t)buf * 2 * IRB_WAVES * nl + (size_t)(1 * IRB_WAVES + wave) * nl;
+      double *sFu = sF0 + (size_t)buf * 2 * NW * (nl + 1) + (size_t)(0 * NW + wave) * (nl + 1);
+      double *sFd = sF0 + (size_t)buf * 2 * NW * (nl + 1) + (size_t)(1 * NW + wave) * (nl + 1);
+      double top_up = 0.0;
 #pragma unroll
       for (int t = 0; t < L; t++) {
         const int i = a + t - pad;
         const E4 e = make_e(G[t], X[t]);
         const double y1 = dd[2 * t] + be[2 * t] * Uin + ga[2 * t] * Din;
         const double y2 = dd[2 * t + 1] + be[2 * t + 1] * Uin + ga[2 * t + 1] * Din;
-        if (t >= pad) {
-          sFu[i + 1] = wcol * (y1 * e.e1 + y2 * e.e2 + cpbv[t]);
-          sFd[i + 1] = wcol * (y1 * e.e3 + y2 * e.e4 + cmbv[t]);
-          if (i == 0) {
-            // the source at the top of the column's first layer
-            const double Bt = Bf[t], Bb = Bf[t + 1];
-            const double b1n = (Bb - Bt) * itau[t];
-            const double b0n = (itau[t] == 0.0) ? 0.5 * (Bt + Bb) : Bt;
-            sFu[0] = wcol * ((y1 * e.e3 - y2 * e.e4) + PI * (b0n + b1n * rq[t]));
-            sFd[0] = 0.0;
-          }
-        }
+        // (no branch per slot: a zero-thickness slot's values go to a dump entry behind the wave's rows)
+        const int lv = t >= pad ? i + 1 : nl;
+        sFu[lv] = wcol * (y1 * e.e1 + y2 * e.e2 + cpbv[t]);
+        sFd[lv] = wcol * (y1 * e.e3 + y2 * e.e4 + cmbv[t]);
+        // up-flux through the top of the lane's slot 0: in lane 0 the column's top (a zero-thickness slot above the
+        // first real layer hands the flux through)
+        if (t == 0) top_up = (y1 * e.e3 - y2 * e.e4) + cp0_top;
+      }
+      if (is_toa) {
+        sFu[0] = wcol * top_up;
+        sFd[0] = 0.0;
       }
       __syncthreads();
-      // sum over the g-points (in g order), reversal to ground-first (radiate.f90:140-154)
+      // sum over the g-points (in g order: a later group continues the sum the earlier ones stored), reversal to
+      // ground-first (radiate.f90:140-154)
       for (int n = threadIdx.x; n < nl; n += blockDim.x) {
-        const double *sF = sF0 + (size_t)buf * 2 * IRB_WAVES * nl;
-        double fu = 0.0, fd = 0.0;
-#pragma unroll
-        for (int w = 0; w < IRB_WAVES; w++) {
-          fu = fu + sF[(size_t)(0 * IRB_WAVES + w) * nl + n];
-          fd = fd + sF[(size_t)(1 * IRB_WAVES + w) * nl + n];
-        }
+        const double *sF = sF0 + (size_t)buf * 2 * NW * (nl + 1);
         const size_t o = (size_t)(c0 + cj) * p.b_out + (size_t)ll * nl + (nz - n);
+        double fu = 0.0, fd = 0.0;
+        if (g0 > 0) { fu = p.ir_fup_a[o]; fd = p.ir_fdn_a[o]; }
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          fu = fu + sF[(size_t)(0 * NW + w) * (nl + 1) + n];
+          fd = fd + sF[(size_t)(1 * NW + w) * (nl + 1) + n];
+        }
         p.ir_fup_a[o] = fu;
         p.ir_fdn_a[o] = fd;
       }
     }
   }
+  __syncthreads();   // the next g-point group reuses the staging buffers and the step tables
+  }
 }
 
-// false when the configuration is outside what the kernel covers: more than 8 g-points, or more
-// than 4 layer slots per lane (nz > 256; an 8-slot instantiation of the earlier form spilled ~500
-// registers and was slower than one full solve per column: 97 vs 37 us per column at nz = 500)
-bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s) {
+// false when the configuration is outside what the kernel covers: more than 8 layer slots per lane (nz > 512)
+// or an LDS image beyond 160 KiB.  force_nw (test hook): 4 selects the four-wave form for 1-4 slots too.
+bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s, int force_nw) {
   const int lmax = std::max((p.nz + 63) / 64, p.force_slots);
-  if (p.ng > IRB_WAVES || lmax > 4 || p.n_ir <= 0 || ncol <= 0) return false;
-  const size_t lds = sizeof(double) * ((size_t)(IRB_TILE + 4 * IRB_WAVES) * ((size_t)p.nz + 1) + 2 * WSCAN_STEPS * 64 * IRB_WAVES);
+  if (lmax > 8 || p.n_ir <= 0 || ncol <= 0 || p.ng < 1) return false;
+  const int nw = (lmax > 4 || p.ng > 8 || force_nw == 4) ? 4 : 8;
+  const size_t lds = sizeof(double) * ((size_t)IRB_TILE * ((size_t)p.nz + 1) + (size_t)4 * nw * ((size_t)p.nz + 2) + (nw == 8 ? 2 * WSCAN_STEPS * 64 * nw : 0));
   if (lds > 160 * 1024) return false;
   using Kern = void (*)(TwoStreamParams, int, int);
-  static const Kern kern[4] = {k_twostream_ir_batch<1>, k_twostream_ir_batch<2>, k_twostream_ir_batch<3>, k_twostream_ir_batch<4>};
-  if (!ensure_max_lds((const void *)kern[lmax - 1])) return false;
+  static const Kern kern8[4] = {k_twostream_ir_batch<1, 8>, k_twostream_ir_batch<2, 8>, k_twostream_ir_batch<3, 8>, k_twostream_ir_batch<4, 8>};
+  static const Kern kern4[8] = {k_twostream_ir_batch<1, 4>, k_twostream_ir_batch<2, 4>, k_twostream_ir_batch<3, 4>, k_twostream_ir_batch<4, 4>,
+                                k_twostream_ir_batch<5, 4>, k_twostream_ir_batch<6, 4>, k_twostream_ir_batch<7, 4>, k_twostream_ir_batch<8, 4>};
+  const Kern k = nw == 8 ? kern8[lmax - 1] : kern4[lmax - 1];
+  if (!ensure_max_lds((const void *)k)) return false;
   // enough blocks to fill the chip a few times over, each with a worthwhile run of columns
   int cpb = (ncol + 3) / 4;
   if (cpb < IRB_TILE) cpb = std::min(ncol, IRB_TILE);
-  const dim3 grid(p.n_ir, 1, (ncol + cpb - 1) / cpb), blk(64 * IRB_WAVES);
-  hipLaunchKernelGGL(kern[lmax - 1], grid, blk, lds, s, p, ncol, cpb);  // layer slots per lane = ceil(nz/64)
+  const dim3 grid(p.n_ir, 1, (ncol + cpb - 1) / cpb), blk(64 * nw);
+  hipLaunchKernelGGL(k, grid, blk, lds, s, p, ncol, cpb);  // layer slots per lane = ceil(nz/64)
   return true;
 }
 

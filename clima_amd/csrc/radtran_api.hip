@@ -1434,7 +1434,10 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   upload_fields(r);
   ensure_w0(r);
   const int nz = r->nz, nl = nz + 1, n = *ncol, nw_ir = r->ir.nw;
-  const int CH = std::min(n, 64);  // columns per launch: bounds the per-column spectra held in HBM
+  // columns per launch: bounds the per-column spectra held in HBM (2.5 GB at 512 layers: 288 GB make that a
+  // non-issue) and sets how many columns share one evaluation of the temperature-independent part -- a block of
+  // the shared-matrix kernel takes a quarter of them: at 64 per launch that part was a fifth of the kernel
+  const int CH = std::min(n, 512);
   const int nchunk = integrate_chunks(r->ir_n);
   const size_t spec = (size_t)nw_ir * nl;
   auto ensure = [](DevBuf<double> &b, size_t count) { if (b.n < count) b.alloc(count); };  // grow-only
@@ -1451,7 +1454,7 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     const int nc = std::min(CH, n - c0);
     TwoStreamParams tb = ts;
     tb.T = r->d_bT.p + (size_t)c0 * nz; tb.T_surface = r->d_bTs.p + c0; tb.b_ncol = nc;
-    // shared-matrix batch kernel (ng <= 8); otherwise one full solve per column
+    // shared-matrix batch kernel (up to 512 layers); otherwise one full solve per column
     const bool shared_ok = r->batch_shared && launch_twostream_ir_batch(tb, nc, r->stream);
     HIPCHK(hipGetLastError());
     if (!shared_ok) {
@@ -2102,7 +2105,8 @@ void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, d
 // (k_twostream), 2 the two-stream part of the fused grid (k_fused, whole-wave form, slots 2..8, ng = 8), 4 the
 // same in the half-wave form (two g-point columns per wave, slots = ceil(nz/32) = 3..7), 5 the same in the
 // paired form (every layer 2m+1 a copy of layer 2m: even nz, slots 2, 4, 6, 8; the caller passes such a column),
-// 3 batched shared-opacity IR kernel (k_twostream_ir_batch<slots>, IR outputs only).
+// 3 batched shared-opacity IR kernel (k_twostream_ir_batch<slots, NW>, IR outputs only: slots 1..4 in blocks of 8
+// g-point waves, 5..8 in blocks of 4), 6 the same with blocks of 4 waves at every slot count.
 // slots = layer slots per lane (>= ceil(nz/64)).  Outputs are TOA-first like the solver's.
 void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, const int *slots, const double *tau,
                            const double *w0, const double *g, const double *bplanck, const double *ir_par,
@@ -2134,7 +2138,7 @@ void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, cons
   TwoStreamParams ts;
   std::memset(&ts, 0, sizeof(ts));
   ts.nz = nz; ts.ng = ng;
-  ts.n_sol = (*form == 3) ? 0 : 1; ts.n_ir = 1;
+  ts.n_sol = (*form == 3 || *form == 6) ? 0 : 1; ts.n_ir = 1;
   ts.tau = d_tau.p; ts.w0 = d_w0.p; ts.g = d_g.p; ts.tau_band = d_tb.p;
   ts.wbin = d_wbin.p; ts.freq = d_freq.p;
   ts.bplanck = d_bp.p; ts.force_slots = *slots;
@@ -2158,7 +2162,7 @@ void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, cons
     d_qm.upload(std::vector<int>{nz});  // the column's source-layer count
     ok = launch_fused_twostream_only(ts, *slots, d_qm.p, nullptr, *form == 4, *form == 5);
   }
-  else if (*form == 3) { ts.b_T = 0; ts.b_Ts = 0; ts.b_out = 0; ok = launch_twostream_ir_batch(ts, 1, nullptr); }
+  else if (*form == 3 || *form == 6) { ts.b_T = 0; ts.b_Ts = 0; ts.b_out = 0; ok = launch_twostream_ir_batch(ts, 1, nullptr, *form == 6 ? 4 : 0); }
   HIPCHK(hipGetLastError());
   if (!ok) throw HipFail{"clima_test_two_stream: this form does not cover the requested shape"};
   HIPCHK(hipDeviceSynchronize());

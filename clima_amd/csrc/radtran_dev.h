@@ -261,7 +261,7 @@ bool launch_opacity(const OpacityParams &p, hipStream_t s);
 bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes);
 bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed);
 // T + c*b_T, T_surface + c*b_Ts, IR spectra + c*b_out for column c of ncol
-bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s);
+bool launch_twostream_ir_batch(TwoStreamParams &p, int ncol, hipStream_t s, int force_nw = 0);
 bool fused_supported(const OpacityParams &op, const TwoStreamParams &ts);
 int fused_half_form(const OpacityParams &op, const TwoStreamParams &ts, int ncol);
 int fused_tiles(const OpacityParams &op);   // opacity tiles per column (size of a column's done[] slice)

@@ -260,7 +260,8 @@ void clima_test_wave_scan(const int *nwaves, const double *a, const double *b, d
  * k_fused in its whole-wave form (slots 2..8, ng 8), 4: the same in the half-wave form (two g-point columns
  * per wave, slots = ceil(nz/32) = 3..7), 5: the same in the paired form (a column of pairwise identical
  * layers -- AdiabatClimate's doubled radiative grid -- even nz, slots 2, 4, 6, 8),
- * 3: k_twostream_ir_batch<slots> (IR only).  Outputs (nz+1) TOA-first. */
+ * 3: k_twostream_ir_batch<slots, NW> (IR only; slots 1..4 in blocks of 8 g-point waves, 5..8 in blocks of 4),
+ * 6: the same in blocks of 4 waves at every slot count.  Outputs (nz+1) TOA-first. */
 void clima_test_two_stream(const int *nz, const int *ng, const int *form, const int *slots, const double *tau,
                            const double *w0, const double *g, const double *bplanck, const double *ir_par,
                            const double *sol_par, const double *wbin, double *ir_fup, double *ir_fdn,

@@ -531,7 +531,8 @@ def test_state_carried_between_calls(O, small_tables):
     _compare(r, o, warm)
 
 
-@pytest.mark.parametrize("nz,ncol", [(50, 7), (30, 70), (300, 5), (1, 3), (64, 9), (65, 9), (100, 5), (150, 9), (193, 4), (256, 3)])
+@pytest.mark.parametrize("nz,ncol", [(50, 7), (30, 70), (300, 5), (1, 3), (64, 9), (65, 9), (100, 5), (150, 9), (193, 4), (256, 3),
+                                     (257, 4), (320, 9), (402, 11), (448, 3), (500, 6), (512, 3)])
 def test_batched_shared_opacity_ir_calls(O, small_tables, nz, ncol, monkeypatch):
     # the RCE Jacobian's loop (clima_adiabat_solve.f90:798-812) in one call: every column equals
     # radiate(..., compute_solar=False, compute_opacity=False) on the same resident opacities
@@ -733,3 +734,81 @@ def test_accessor_shapes_and_channels(small_tables):
     u = r.zenith_u
     assert len(u) == 4 and np.all((u > 0) & (u < 1)) and abs(np.sum(r.zenith_weights) - 1) < 1e-14
     assert r.f_total.shape == (51,)
+
+
+def test_results_read_through_getters_after_an_unsynchronised_timed_out_call(monkeypatch):
+    """radiate_resident + a spectra getter, with no radtran_synchronize in between: the getter itself must
+    notice the expired hand-off and hand out the repaired results (round 2 copied out stale spectra)."""
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    tables = S.modern_earth_tables(nw=400)
+    nz = 200
+    col = S.modern_earth_column(nz)
+    ref = Radtran(tables, nz, 4, 0.2)
+    ref.fused = False
+    ref.radiate(*col.args())
+    want_up, want_tb = np.array(ref.wrk_sol.fup_a), np.array(ref.wrk_ir.tau_band)
+    want_opr = ref.opr()
+    monkeypatch.setenv("CLIMA_HIP_FUSED_SPINS", "0")
+    r = Radtran(tables, nz, 4, 0.2)
+    monkeypatch.delenv("CLIMA_HIP_FUSED_SPINS")
+    other = S.modern_earth_column(nz)
+    other["T"] = np.asarray(other["T"]) + 7.0
+    r.radiate(*other.args())                      # something else in the buffers first
+    n0 = r.fused_fallbacks
+    r.upload_column(*col.args())
+    r.radiate_resident()
+    got_up = np.array(r.wrk_sol.fup_a)            # first touch after the call: a 2-D getter
+    assert r.fused_fallbacks > n0
+    np.testing.assert_array_equal(got_up, want_up)
+    np.testing.assert_array_equal(np.array(r.wrk_ir.tau_band), want_tb)
+    r.radiate_resident()
+    for a, b in zip(r.opr(), want_opr):           # and radtran_opr_get
+        np.testing.assert_array_equal(a, b)
+
+
+def test_timed_out_opacity_pass_is_not_repaired_from_a_replaced_column(monkeypatch):
+    """upload A, opacity pass (times out), upload B, compute_opacity=False pass, synchronize: recomputing the
+    opacities from column B is not what was asked for -- the library says so instead."""
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran, ClimaException
+    tables = S.modern_earth_tables(nw=400)
+    nz = 200
+    col = S.modern_earth_column(nz)
+    monkeypatch.setenv("CLIMA_HIP_FUSED_SPINS", "0")
+    r = Radtran(tables, nz, 4, 0.2)
+    monkeypatch.delenv("CLIMA_HIP_FUSED_SPINS")
+    r.upload_column(*col.args())
+    r.radiate_resident()
+    warm = S.Column(col)
+    warm["T"] = np.asarray(col["T"]) + 3.0
+    r.upload_column(*warm.args())
+    r.radiate_resident(False, False)
+    with pytest.raises(ClimaException, match="column has been replaced"):
+        r.synchronize()
+    # the caller repeats the steps: a fresh opacity pass clears the condition
+    r.upload_column(*col.args())
+    r.radiate_resident()
+    r.synchronize()
+
+
+def test_state_after_a_column_batch_is_the_last_columns(O):
+    """After radtran_toa_fluxes_batch the handle's level rows AND its per-bin spectra are the last column's
+    (round 2 left the spectra of an earlier call beside the new level rows)."""
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    tables = S.modern_earth_tables(nw=60)
+    nz = 100
+    cols = S.perturbed_columns(5, nz=nz, seed=3)
+    r = Radtran(tables, nz, 2, 0.2)
+    r.radiate(*cols[0].args())
+    isr, olr = r.TOA_fluxes_batch(cols)
+    up_n, up_a, tb = np.array(r.wrk_ir.fup_n), np.array(r.wrk_ir.fup_a), np.array(r.wrk_sol.tau_band)
+    am = np.array(r.wrk_sol.amean)
+    one = Radtran(tables, nz, 2, 0.2)
+    one.coop_items = 0     # the batch runs the lane-per-item opacity kernel inside the fused grid: so does this call
+    assert one.TOA_fluxes(*cols[-1].args()) == (isr[-1], olr[-1])
+    np.testing.assert_array_equal(up_n, np.array(one.wrk_ir.fup_n))
+    np.testing.assert_array_equal(up_a, np.array(one.wrk_ir.fup_a))
+    np.testing.assert_array_equal(tb, np.array(one.wrk_sol.tau_band))
+    np.testing.assert_array_equal(am, np.array(one.wrk_sol.amean))
