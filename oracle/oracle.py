@@ -55,7 +55,8 @@ def lib(variant=""):
     the same source compiled with contraction (conditioning yardstick only)."""
     if variant not in _libs:
         build()
-        L = C.CDLL(os.path.join(_HERE, "liborc%s.so" % ("_" + variant if variant else "")))
+        # CLIMA_ORACLE_DIR: another build of the same libraries (the sanitizer build of tools/sanitize.sh)
+        L = C.CDLL(os.path.join(os.environ.get("CLIMA_ORACLE_DIR") or _HERE, "liborc%s.so" % ("_" + variant if variant else "")))
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp]
         L.orc_destroy.argtypes = [C.c_void_p]

@@ -1,0 +1,147 @@
+/* Sanitizer driver for the HOST side of libclima_radtran_hip (clima_amd/csrc/radtran_api.hip: ~2 000 lines of
+ * manual buffer management), built with host-only AddressSanitizer + UndefinedBehaviorSanitizer (tools/sanitize.sh;
+ * GPU sanitizers are not available on this pool).  Runs WITHOUT a GPU: construction, every validation and error
+ * path, the getters / setters, opacities2yaml's two-step string hand-over, and destruction of a handle in every
+ * state -- what the reference's CI checks with valgrind on its own driver
+ * (.github/workflows/test.yaml:48-55).  Exit code 0 and no sanitizer / leak report = clean. */
+#include "../../include/clima_radtran_hip.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NZ 10
+#define NSP 3
+#define NP 1
+#define NW 8
+#define NG 8
+#define NPR 3
+#define NT 4
+#define NRAD 5
+
+static char err[CLIMA_ERR_LEN + 1];
+static int fails = 0;
+static void expect(int cond, const char *what) {
+  if (!cond) { fprintf(stderr, "abi_driver: FAILED: %s (err: %s)\n", what, err); fails++; }
+}
+
+static void *build(int stop_before_end) {
+  void *h = NULL;
+  allocate_radtran(&h);
+  double wavl[NW + 1];
+  for (int i = 0; i <= NW; i++) wavl[i] = 100.0 * pow(1.0e4, (double)i / NW);
+  int nz = NZ, nsp = NSP, np = NP, nw = NW, zero = 0;
+  radtran_create_begin(h, &zero, &nsp, &np, &nw, wavl, err);
+  expect(strstr(err, "can not be less than 1") != NULL, "nz = 0 refused");
+  radtran_create_begin(h, &nz, &nsp, &np, &nw, wavl, err);
+  expect(err[0] == 0, "create_begin");
+  double wts[NG], log10P[NPR] = {-4.0, -1.0, 1.0}, temp[NT] = {100.0, 250.0, 400.0, 700.0};
+  for (int g = 0; g < NG; g++) wts[g] = 1.0 / NG;
+  double *k = malloc(sizeof(double) * NW * NT * NPR * NG);
+  for (int i = 0; i < NW * NT * NPR * NG; i++) k[i] = -24.0 + 0.001 * (i % 977);
+  int ng = NG, npr = NPR, nt = NT;
+  for (int sp = 1; sp <= 2; sp++) {
+    radtran_add_ktable(h, &sp, &ng, wts, &npr, log10P, &nt, temp, k, err);
+    expect(err[0] == 0, "add_ktable");
+  }
+  int bad_sp = 9;
+  radtran_add_ktable(h, &bad_sp, &ng, wts, &npr, log10P, &nt, temp, k, err);
+  expect(strstr(err, "out of range") != NULL, "k-table species index refused");
+  int ng4 = 4;
+  int sp3 = 3;
+  radtran_add_ktable(h, &sp3, &ng4, wts, &npr, log10P, &nt, temp, k, err);
+  expect(strstr(err, "same g-points") != NULL, "mismatched g-point count refused");
+  free(k);
+  double xs0[NW], xs1[NW * NT];
+  for (int l = 0; l < NW; l++) { xs0[l] = 1e-27 * (1 + l); for (int t = 0; t < NT; t++) xs1[l * NT + t] = -46.0 + 0.1 * t; }
+  int ty = CLIMA_XS_RAYLEIGH, d0 = 0, d1 = 1, s1 = 3, s2 = 3, none = -1;
+  radtran_add_xsection(h, &ty, &d0, &s1, &none, &zero, NULL, xs0, err); expect(err[0] == 0, "rayleigh");
+  radtran_add_xsection(h, &ty, &d1, &s1, &none, &nt, temp, xs1, err); expect(strstr(err, "0-D") != NULL, "1-D Rayleigh refused");
+  ty = CLIMA_XS_CIA;
+  radtran_add_xsection(h, &ty, &d1, &s1, &s2, &nt, temp, xs1, err); expect(err[0] == 0, "cia");
+  ty = CLIMA_XS_PHOTOLYSIS;
+  radtran_add_xsection(h, &ty, &d0, &s1, &none, &zero, NULL, xs0, err); expect(err[0] == 0, "photolysis");
+  ty = 17;
+  radtran_add_xsection(h, &ty, &d0, &s1, &none, &zero, NULL, xs0, err); expect(strstr(err, "unknown") != NULL, "unknown xs type refused");
+  int lh2o = 1;
+  radtran_set_water_continuum(h, &lh2o, &nt, temp, xs1, xs1, err); expect(err[0] == 0, "continuum");
+  double radii[NRAD] = {1e-6, 3e-6, 1e-5, 3e-5, 1e-4}, pw[NW * NRAD];
+  for (int i = 0; i < NW * NRAD; i++) pw[i] = 0.5;
+  int pind = 1, nrad = NRAD;
+  radtran_add_particle(h, &pind, &nrad, radii, pw, pw, pw, err); expect(err[0] == 0, "particle");
+  double badw[3] = {150.0, 300.0, 999.0};
+  int three = 3;
+  radtran_set_channels(h, &three, badw, &three, badw, err);
+  expect(strstr(err, "not compatible") != NULL, "incompatible channel refused");
+  int nir = NW - 2, nsol = NW - 1;
+  radtran_set_channels(h, &nir, wavl + 3, &nsol, wavl, err); expect(err[0] == 0, "channels");
+  double ph[NW];
+  for (int l = 0; l < NW; l++) ph[l] = 1e-8;
+  int nph = NW - 2, wrong = 3;
+  radtran_set_photons_sol(h, &wrong, ph, err); expect(strstr(err, "wrong size") != NULL, "photons size refused");
+  radtran_set_photons_sol(h, &nph, ph, err); expect(err[0] == 0, "photons");
+  radtran_set_names(h, "H2O\nCO2\nN2", "HCaer1", err); expect(err[0] == 0, "names");
+  radtran_set_names(h, "H2O\nCO2", "HCaer1", err); expect(err[0] != 0, "wrong number of names refused");
+  radtran_set_opacity_labels(h, "RandomOverlapResortRebin", "MT_CKD", "khare1984", err);
+  if (stop_before_end) return h;
+  int nzen = 4;
+  double alb = 0.2;
+  radtran_create_end(h, &nzen, &alb, err);   /* no GPU here: must fail with a message, leaving a destroyable handle */
+  return h;
+}
+
+int main(void) {
+  for (int rep = 0; rep < 3; rep++) {
+    void *h = build(rep == 1);
+    const int constructed = err[0] == 0 && rep != 1;   /* only on a GPU box */
+    if (!constructed && rep != 1) expect(strstr(err, "HIP") != NULL || strstr(err, "device") != NULL, "create_end reports the missing device");
+    /* the YAML hand-over: _1 allocates, _2 copies and frees */
+    int len = 0;
+    void *cp = NULL;
+    radtran_opacities2yaml_wrapper_1(h, &len, &cp);
+    char *buf = malloc((size_t)len + 1);
+    radtran_opacities2yaml_wrapper_2(h, &cp, &len, buf);
+    expect(strstr(buf, "k-distributions: [H2O, CO2]") != NULL && strstr(buf, "particle-xs: [{name: HCaer1, data: khare1984}]") != NULL, "opacities2yaml text");
+    free(buf);
+    /* getters / setters of a handle in any state */
+    double v = 0.0;
+    bool hs = false;
+    radtran_has_hard_surface_get(h, &hs); radtran_has_hard_surface_set(h, &hs);
+    radtran_ir_tau_min_get(h, &v); radtran_ir_tau_min_set(h, &v);
+    radtran_diurnal_fac_get(h, &v); radtran_photon_scale_factor_get(h, &v);
+    int n1 = 0, n2 = 0, n3 = 0;
+    radtran_zenith_u_get_size(h, &n1);
+    radtran_f_total_get_size(h, &n1);
+    radtran_comm_get(h, &n1, &n2, &n3);
+    expect(n1 == 0, "no communicator");
+    void *sub = NULL;
+    radtran_ir_get(h, &sub); rtchannel_wavl_get_size(sub, &n1);
+    expect(n1 == NW - 2, "ir channel edges");
+    double edges[NW];
+    rtchannel_wavl_get(sub, &n1, edges); rtchannel_freq_get(sub, &n1, edges);
+    /* entry points that need a constructed object refuse politely */
+    int one = 1;
+    radtran_radiate_resident(h, &one, &one, err);
+    if (!constructed) expect(strstr(err, "not constructed") != NULL, "radiate on an unconstructed handle refused");
+    radtran_synchronize(h, err);
+    radtran_set_bin_shard(h, &one, &one, err);
+    expect(err[0] != 0, "invalid shard / unconstructed refused");
+    char id[CLIMA_COMM_ID_BYTES];
+    radtran_comm_unique_id(id, err);
+    radtran_comm_init_rank(h, &one, &n2, id, err);
+    if (!constructed) expect(strstr(err, "not constructed") != NULL, "communicator on an unconstructed handle refused");
+    radtran_comm_destroy(h);
+    double wv[3] = {2e2, 1e3, 1e5}, Pc[3] = {1e6, 1e4, 1e2}, t9[9] = {0};
+    int i3 = 3, i2 = 2;
+    radtran_set_custom_optical_properties(h, &i3, wv, &i3, Pc, &i2, &i3, t9, &i3, &i3, t9, &i3, &i3, t9, err);
+    expect(err[0] != 0, "custom optical properties: bad shape / unconstructed refused");
+    radtran_unset_custom_optical_properties(h);
+    deallocate_radtran(h);
+  }
+  deallocate_radtran(NULL);
+  radtran_synchronize(NULL, err);
+  expect(strstr(err, "invalid Radtran handle") != NULL, "null handle refused");
+  if (fails) return 1;
+  printf("abi_driver: ok\n");
+  return 0;
+}
