@@ -27,7 +27,7 @@ What the one JSON line carries (rank 0):
                  `fp64_issue_frac` = VALU instructions per launch (PMC pass under profiles/) x 4
                  cycles / (1024 SIMDs x 2.4 GHz) / kernel time; `traffic` from the PMC pass.  Both PMC
                  figures are printed only when clima_amd/csrc/kernels.hip still has the hash recorded
-                 beside the PMC summary (profiles/r02_pmc.json) -- otherwise null.
+                 beside the PMC summary (profiles/r03_pmc.json) -- otherwise null.
   algorithmic    N_PT, N_T and both byte variants of SURVEY.md 8(d).
   cpu_baseline   the oracle on this box's host cores, same workload (a reported baseline).
 
@@ -58,7 +58,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 SIMDS, CLOCK_GHZ, F64_CYCLES = 1024, 2.4, 4.0   # 256 CUs x 4 SIMDs; one wave64 f64 instruction per SIMD per 4 cycles
 KERNELS = ["prep", "opacity", "twostream", "integrate"]
 EVENT_STRIDE = 16  # HIP events around the dominant kernel on every 16th launch of the timed region (first one included)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 KERNEL_SRC = os.path.join(ROOT, "clima_amd", "csrc", "kernels.hip")
 
 

@@ -1,15 +1,28 @@
 // kernels.hip -- hand-written gfx950 (CDNA4) kernels for Clima's radiate() hot path.
 //
-//   k_prep        per-column pre-pass shared by every bin: log10P, columns, pair_reuse,
-//                 interpolation brackets/weights (compute_opacity pre-pass,
-//                 src/radtran/clima_radtran_types.f90:599-633 + dintrv bracketing)
-//   k_opacity     one LANE per (bin, layer): k-table / CIA / continuum / Rayleigh / Mie
-//                 gather + random-overlap resort-rebin (types.f90:640-888).  The 64-key
-//                 resort is a register-resident Batcher network (v_min_f64/v_max_f64).
-//   k_twostream   one WORKGROUP per (channel, bin): Toon two-stream, layer-parallel
-//                 coefficient assembly staged in LDS, Thomas solve per g-point column,
-//                 g-/zenith-weighted level fluxes (radiate.f90:50-158, twostream.f90)
-//   k_integrate   spectral integration + f_total (radiate.f90:184-192, clima_radtran.f90:316)
+//   k_prep             per-column pre-pass shared by every bin: log10P, columns, continuum weights, interpolation
+//                      brackets / weights of every table axis (compute_opacity pre-pass,
+//                      src/radtran/clima_radtran_types.f90:599-633 + dintrv bracketing); spare blocks clear what the
+//                      two-stream forms that add partial sums accumulate into.  One launch, a column dimension.
+//   k_opacity8         one LANE per (bin, source layer): k-table / CIA / continuum / Rayleigh / Mie gather +
+//                      random-overlap resort-rebin (types.f90:640-888); the 64-key resort is a register-resident
+//                      Batcher network (v_min_f64 / v_max_f64), the rebin the "window" form.
+//   k_opacity_coop     NG = 8, 16 or 32 lanes per (bin, source layer): the sort across the group (DPP / ds_swizzle);
+//                      few-item calls (a bin-sharded rank) and the 16- / 32-g-point settings.
+//   k_opacity_generic  any other g-point count 1..32 (one wave per item, LDS bitonic sort): completeness path.
+//   k_twostream_w      one WAVE per (channel, bin, g-point) -- twostream_p_body: lane q owns a chunk of layers in
+//                      registers, per-lane elimination with flux boundary conditions, the chunks joined by DPP wave
+//                      scans (3x3 projective suffix scan + affine prefix scan); half-wave (two columns per wave) and
+//                      paired (AdiabatClimate's doubled grid) forms (radiate.f90:50-158, twostream.f90:10-295).
+//   k_twostream        one WORKGROUP per (channel, bin), LDS image + 16-chunk decomposition: beyond 512 layers.
+//   k_twostream_ir_batch  many temperature columns on one set of opacities (the RCE Jacobian,
+//                      src/adiabat/clima_adiabat_solve.f90:798-812): the temperature-independent part once per
+//                      (bin, g-point); blocks of 8 waves up to 256 layers, of 4 (one per SIMD) up to 512.
+//   k_fused            the production grid of a compute_opacity call: the opacity tiles of k_opacity8 followed, in
+//                      the SAME launch, by the two-stream blocks of twostream_p_body, each waiting (bounded) for the
+//                      tiles of its bin -- write-through hand-off, no cache-wide fence.
+//   k_integrate_one    spectral integration (radiate.f90:184-192); f_total (clima_radtran.f90:316) on the host from
+//                      the four level rows it fetches anyway.
 //
 // All arithmetic is IEEE binary64.  No MFMA: there is no dense contraction on this path.
 #include "radtran_dev.h"
@@ -460,8 +473,7 @@ __device__ __forceinline__ double ld_opr(const double *p) {
 }
 
 #ifdef CLIMA_STAMPS
-__device__ long long *g_stamp_buf = nullptr;
-__device__ int g_stamp_step = 0;
+__device__ long long *g_stamp_buf = nullptr;   // (two-stream blocks of the diagnostic build find the buffer here)
 #endif
 
 // Random-overlap resort + rebin for NG = 8 (k_rorr, types.f90:826-852), one lane per
@@ -593,7 +605,8 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
                                           double (*sI)[OP_THREADS], const int tid, const int tile,
                                           const double *s_wxy, const double *s_E,
                                           const double *s_Ew, const double *rW,
-                                          double (&out)[8]) {
+                                          double (&out)[8], long long *stamps = nullptr, const int stamp_slot = 0) {
+  (void)stamps; (void)stamp_slot;   // diagnostic build only: where the "sort done" stamp of this mixing step goes
   double key[64];
   bool ysorted = true, xsorted = true;
 #pragma unroll
@@ -654,7 +667,7 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
 #undef CE_L32_REST
 #undef CE_X
 #undef CE
-  STAMP(g_stamp_buf, 30 + g_stamp_step);
+  STAMP(stamps, stamp_slot);
   if constexpr (RM == 0) {
     rebin_window(key, xys, s_wxy, s_Ew, rW, out);
     return;
@@ -818,7 +831,11 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   #pragma unroll
       for (int u = 0; u < AB; u++) {
         const AbsEntry &x = p.abs[e0 + u];
+#ifdef CLIMA_EXP_NODEP   // timing experiment only (WRONG results): the table loads do not wait for the bracket index
+        const double *base = x.data + (x.nT ? (size_t)l * x.nT : (size_t)l);
+#else
         const double *base = x.data + (x.nT ? (size_t)l * x.nT + ixx[u] : (size_t)l);
+#endif
         v0[u] = base[0];
         v1[u] = base[x.nT ? 1 : 0];
       }
@@ -911,10 +928,10 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
       for (int g = 0; g < NG; g++) tk[g] = kc[g];
     } else {
 #ifdef CLIMA_STAMPS
-      if (tile == 100 && threadIdx.x == 0) { g_stamp_buf = p.stamps; g_stamp_step = s; }
+      if (tile == 100 && threadIdx.x == 0) g_stamp_buf = p.stamps;
 #endif
       double out[NG];
-      rorr_mix8<RM>(tk, kc, sI, tid, tile, s_wxy, s_E, s_Ew, rW, out);
+      rorr_mix8<RM>(tk, kc, sI, tid, tile, s_wxy, s_E, s_Ew, rW, out, p.stamps, 21 + s);   // (slots 22..25: 32.. belong to the two-stream blocks)
 #pragma unroll
       for (int g = 0; g < NG; g++) tk[g] = out[g];
       STAMP(p.stamps, 4 + 3 * s);

@@ -88,3 +88,30 @@ def test_partition_is_balanced_and_complete():
         loads = [cost[s[0]:s[0] + s[1]].sum() for s in shards]
         assert max(loads) <= 1.05 * cost.sum() / world + cost.max()
         assert sum(s[3] for s in shards) == 600 and sum(s[5] for s in shards) == 600
+
+
+def _id_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from clima_amd.radtran import Radtran
+    # what bench.py does for N > 1: rank 0 draws the id of the LIBRARY's communicator, torch.distributed hands it round
+    ids = [Radtran.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    q.put((rank, bytes(ids[0])))
+    dist.destroy_process_group()
+
+
+def test_communicator_id_reaches_every_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len(res[0]) == 128 and res[0] == res[1] and any(res[0])

@@ -18,6 +18,8 @@ for nw in [int(a) for a in sys.argv[1:]] or [100, 200, 400, 1000]:
     ts = []
     for _ in range(100):
         t0 = time.perf_counter(); r.TOA_fluxes(*a); ts.append(time.perf_counter() - t0)
+    r.bench_toa_fluxes(10, *a)
+    tc = r.bench_toa_fluxes(100, *a)      # the same call timed inside the library (no ctypes layer)
     r.upload_column(*a)
     for _ in range(20): r.radiate_resident()
     r.synchronize()
@@ -29,6 +31,6 @@ for nw in [int(a) for a in sys.argv[1:]] or [100, 200, 400, 1000]:
     for _ in range(30): r.radiate_resident()
     r.synchronize()
     ks = [r.kernel_time(i) for i in range(4)]
-    print("nw %4d x %d layers (%d source layers): sync TOA_fluxes median %.1f us, resident %.1f us/call | " % (nw, nzr, nzr // 2, 1e6 * np.median(ts), res * 1e6) +
+    print("nw %4d x %d layers (%d source layers): sync TOA_fluxes median %.1f us (inside the library: %.1f us), resident %.1f us/call | " % (nw, nzr, nzr // 2, 1e6 * np.median(ts), float(np.median(tc)), res * 1e6) +
           ", ".join("%s %.1f" % (n, 1e3 * ms / max(c, 1)) for n, (ms, c) in zip(["prep", "opacity|fused", "twostream", "integrate"], ks) if c), flush=True)
     del r

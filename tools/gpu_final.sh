@@ -1,0 +1,38 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- 'bash tools/gpu_final.sh r03'): everything the round's final profiles/ come from,
+# written under gpurun_out/<tag>_*.  tools/finalize_profiles.sh (run in the build container afterwards) condenses
+# it into profiles/.  rocprofv3 is always called with the program itself behind `--` (python3 bench.py ...), PMC
+# passes one counter set at a time and never combined with other trace domains (tools/gpu_profile.sh).
+set -o pipefail
+tag=${1:-r03}
+o=gpurun_out
+mkdir -p $o
+run() { name=$1; shift; echo "== $name: $*"; "$@" > $o/${tag}_$name 2> $o/${tag}_$name.err || { echo "FAILED: $name"; tail -5 $o/${tag}_$name.err; return 1; }; }
+# ---- bench lines: the driver's own command, the default command, configs 3 / 4 / 5
+run bench_line_steps20.json python3 bench.py --gpus 1 --steps 20 --warmup 5 || exit 1
+run bench_line_default.json python3 bench.py || exit 1
+run bench_line_config3.json python3 bench.py --config 3 --no-cpu-baseline || exit 1
+run bench_line_config4.json python3 bench.py --config 4 --no-cpu-baseline || exit 1
+run bench_line_config5.json python3 bench.py --config 5 --no-cpu-baseline || exit 1
+# ---- one rank's share of an N-GPU step rehearsed on one GPU, through the LIBRARY's own RCCL step (one-rank
+#      communicator + the bin shard (0, N)): configs 2 and 5
+for n in 2 4 8; do
+  CLIMA_BENCH_FORCE_DIST=1 CLIMA_BENCH_FAKE_SHARD=0,$n run bench_line_fake_shard_0_of_$n.json python3 bench.py --no-cpu-baseline || exit 1
+  CLIMA_BENCH_FORCE_DIST=1 CLIMA_BENCH_FAKE_SHARD=0,$n run bench_line_config5_fake_shard_0_of_$n.json python3 bench.py --config 5 --no-cpu-baseline || exit 1
+done
+CLIMA_BENCH_FORCE_DIST=1 run bench_line_one_rank_comm.json python3 bench.py --no-cpu-baseline || exit 1
+CLIMA_BENCH_FORCE_DIST=1 CLIMA_BENCH_TORCH_ALLREDUCE=1 run bench_line_one_rank_torch.json python3 bench.py --no-cpu-baseline || exit 1
+# ---- kernel statistics + PMC passes of the default workload
+bash tools/gpu_profile.sh $tag || exit 1
+# ---- sweeps
+run doubled_grid.txt python3 tools/gpu_doubled_grid.py 50 100 200 || exit 1
+run adiabat_like.txt python3 tools/gpu_adiabat_like.py || exit 1
+run nz_sweep.txt python3 tools/gpu_nz_sweep.py || exit 1
+run ng_sweep.txt python3 tools/gpu_ng_sweep.py || exit 1
+run ir_batch.txt python3 tools/gpu_ir_batch.py 50 100 200 249 || exit 1
+# ---- per-phase stamps and the block timeline (the -DCLIMA_STAMPS build, when present)
+if [ -f clima_amd/csrc/libclima_radtran_hip_stamps.so ]; then
+  run stamps.txt python3 tools/gpu_stamps.py || exit 1
+  run timeline.txt python3 tools/gpu_timeline.py || exit 1
+fi
+echo "final pass done: $o/${tag}_*"

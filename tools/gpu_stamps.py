@@ -27,8 +27,8 @@ for sp in range(5):
     a = s[2 + 3 * sp]
     print("species %d interp %7d" % (sp, a - prev))
     if sp > 0:
-        print("   sort          %7d" % (s[30 + sp] - a))
-        print("   rebin         %7d" % (s[4 + 3 * sp] - s[30 + sp]))
+        print("   sort          %7d" % (s[21 + sp] - a))
+        print("   rebin         %7d" % (s[4 + 3 * sp] - s[21 + sp]))
         prev = s[4 + 3 * sp]
     else:
         prev = a
