@@ -152,7 +152,13 @@ def test_single_scattering_albedo_left_to_the_fused_grid_is_materialised_on_dema
     """The fused grid's opacity tiles do not write w0 (its two-stream part forms it from the layers' scattering
     optical depth); whoever asks for it afterwards -- the optical-property accessor, an IR-only call on the
     stored opacities -- gets the array formed by the expression of the tile's store: bitwise what the
-    separate launches (which do write it) leave."""
+    separate launches (which do write it) leave.
+    NOTE what this does and does not say: the materialised array is `min(0.99999, scat / tau)` by true division
+    (the reference's expression, types.f90:869-875), whereas the fused solve that ran BEFORE it was asked for
+    used `scat * rcp(tau)` with the correctly rounded reciprocal -- up to 1 ulp from that quotient
+    (kernels.hip twostream_p_body, `w0_from_scat`).  The exposed w0 is therefore the reference's, not bit for
+    bit the one the fused two-stream solve consumed; the fluxes of the two launch forms agree to 1e-11
+    (tests/test_gpu_parity.py::_compare runs both)."""
     tb, r, col = nominal
     assert r.fused
     r.radiate(*col.args())
