@@ -321,3 +321,44 @@ def test_doubled_radiative_grid_takes_the_paired_two_stream_form(O, nz_adiabat, 
     col2["T"][nzr // 2] *= 1.0 + 1.0e-9
     _compare_once(r, o, col2)
     np.testing.assert_allclose(np.array(r.f_total), f_pair, rtol=1e-6, atol=1e-9 * np.max(np.abs(f_pair)))
+
+
+def test_rce_jacobian_batch_on_the_402_layer_doubled_grid_at_full_size(O):
+    """The RCE Jacobian's radiative work at AdiabatClimate's default resolution (nz = 200 -> 402-layer doubled
+    radiative grid, src/adiabat/clima_adiabat.f90:729-773; nz_r + 1 IR-only calls on unchanged opacities,
+    clima_adiabat_solve.f90:768-822) through radtran_radiate_ir_batch at config 2's spectral size: every one of the
+    403 columns against the library's own one-at-a-time IR-only call, three of them against the oracle."""
+    from clima_amd import synthetic as S
+    from clima_amd.atmosphere import copy_atm_to_radiative_grid
+    from clima_amd.radtran import Radtran
+    tb = S.modern_earth_tables()
+    col = S.Column(copy_atm_to_radiative_grid(S.modern_earth_column(200)))
+    nz = len(col["T"])
+    assert nz == 402
+    r = Radtran(tb, nz, 4, 0.15)
+    r.radiate(*col.args())
+    ncol = nz + 1
+    T = np.repeat(np.asarray(col["T"])[:, None], ncol, axis=1)
+    Ts = np.full(ncol, float(col["T_surface"]))
+    Ts[0] *= 1.01
+    for c in range(1, ncol):
+        T[c - 1, c] *= 1.01
+    fup, fdn, ftot = r.radiate_ir_batch(Ts, T)
+    scale = np.max(np.abs(fup))
+    for c in range(ncol):
+        w = S.Column(col)
+        w["T"] = T[:, c].copy()
+        w["T_surface"] = Ts[c]
+        r.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+        assert np.max(np.abs(fup[:, c] - np.array(r.wrk_ir.fup_n))) <= 1e-11 * scale, c
+        assert np.max(np.abs(fdn[:, c] - np.array(r.wrk_ir.fdn_n))) <= 1e-11 * scale, c
+        assert np.max(np.abs(ftot[:, c] - np.array(r.f_total))) <= 1e-11 * max(scale, np.max(np.abs(ftot))), c
+    o = O.OracleRadtran(tb, nz, 4, 0.15)
+    o.radiate(*col.args())
+    for c in (0, 137, 402):
+        w = S.Column(col)
+        w["T"] = T[:, c].copy()
+        w["T_surface"] = Ts[c]
+        o.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+        assert np.max(np.abs(fup[:, c] - o.wrk_ir.fup_n)) <= 1e-9 * np.max(np.abs(o.wrk_ir.fup_n))
+        assert np.max(np.abs(ftot[:, c] - o.f_total)) <= 1e-9 * np.max(np.abs(o.f_total))
