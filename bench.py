@@ -185,6 +185,9 @@ def main():
             rad.finish_reduced()              # f_total from the reduced fluxes
 
     def barrier():
+        # the library's stream first: its own collectives (a communicator of its own) have drained on every rank
+        # before torch's barrier runs, so kernels of the two communicators never wait on each other on one GPU
+        rad.synchronize()
         if dist_on:
             dist.barrier()
         rad.synchronize()

@@ -812,3 +812,30 @@ def test_state_after_a_column_batch_is_the_last_columns(O):
     np.testing.assert_array_equal(up_a, np.array(one.wrk_ir.fup_a))
     np.testing.assert_array_equal(tb, np.array(one.wrk_sol.tau_band))
     np.testing.assert_array_equal(am, np.array(one.wrk_sol.amean))
+
+
+@pytest.mark.parametrize("ng,nz", [(4, 50), (12, 70), (16, 130), (32, 40)])
+def test_batched_shared_opacity_ir_calls_at_other_g_point_counts(O, ng, nz):
+    """radtran_radiate_ir_batch with a k-distribution setting other than 8 g-points: round 2 fell back to one full
+    solve per column; the shared-matrix kernel now takes the g-points in groups of four (k_twostream_ir_batch<L, 4>)."""
+    from clima_amd import synthetic as S
+    tb = S.modern_earth_tables(nw=12, ng=ng, seed=40 + ng)
+    col = S.modern_earth_column(nz)
+    r, o = _pair(O, tb, nz, 2, 0.25)
+    r.radiate(*col.args())
+    o.radiate(*col.args())
+    ncol = 5
+    T = np.repeat(np.asarray(col["T"])[:, None], ncol, axis=1)
+    Ts = np.full(ncol, float(col["T_surface"]))
+    Ts[1] += 2.0
+    for c in range(2, ncol):
+        T[(7 * c) % nz, c] += 3.0
+    fup, fdn, ftot = r.radiate_ir_batch(Ts, T)
+    for c in range(ncol):
+        w = S.Column(col)
+        w["T"] = T[:, c].copy()
+        w["T_surface"] = Ts[c]
+        o.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+        assert _scaled(fup[:, c], o.wrk_ir.fup_n) <= TOL_LEVEL
+        assert _scaled(fdn[:, c], o.wrk_ir.fdn_n) <= TOL_LEVEL
+        assert _scaled(ftot[:, c], o.f_total) <= TOL_LEVEL
