@@ -1226,6 +1226,20 @@ __device__ __forceinline__ double group_sum(double v) {
   else return v;
 }
 
+// blocks of 4 waves per CU the kernel is compiled for: its lane exchanges make it latency-bound, so waves per SIMD count
+// (measured, profiles/r03_coop_ab.txt: 16 g-points at three waves per SIMD instead of two -- 168 registers, 14-22
+// scratch accesses outside the sort -- 610 -> 541 us; 8 g-points forced from three to four: slower, left alone;
+// 32 g-points at two instead of one: 4.67 -> 2.92 ms)
+#ifndef COOP_BLOCKS_8
+#define COOP_BLOCKS_8 1
+#endif
+#ifndef COOP_BLOCKS_16
+#define COOP_BLOCKS_16 3
+#endif
+#ifndef COOP_BLOCKS_32
+#define COOP_BLOCKS_32 2
+#endif
+#define COOP_MIN_BLOCKS(NG) ((NG) == 8 ? COOP_BLOCKS_8 : (NG) == 16 ? COOP_BLOCKS_16 : COOP_BLOCKS_32)
 template <int NG>
 struct CoopSort {
   // one step with partner position pos ^ X restricted to partners in another lane: lane ^ LM, register
@@ -1235,8 +1249,15 @@ struct CoopSort {
     double b[NG];
 #pragma unroll
     for (int r = 0; r < NG; r++) b[r] = swz_xor<LM>(key[r ^ RM]);
+    // the lane of the lower position keeps the minima, the other one the maxima: one v_min_f64 or one v_max_f64
+    // per key under the lanes' exec masks (a compare and a 64-bit select per key took twice the instructions)
+    if (lower) {
 #pragma unroll
-    for (int r = 0; r < NG; r++) key[r] = ((b[r] < key[r]) == lower) ? b[r] : key[r];
+      for (int r = 0; r < NG; r++) key[r] = dmin(key[r], b[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < NG; r++) key[r] = dmax(key[r], b[r]);
+    }
   }
   template <int X>
   static __device__ __forceinline__ void intra(double (&key)[NG]) {  // partner register r ^ X, X < NG
@@ -1275,19 +1296,29 @@ struct CoopSort {
 };
 
 template <int NG, bool CUSTOM>
-__global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
+__global__ __launch_bounds__(OP_THREADS, COOP_MIN_BLOCKS(NG)) void k_opacity_coop(OpacityParams p) {
   constexpr int N2 = NG * NG, GROUPS = OP_THREADS / NG;
   constexpr unsigned long long IDX_MASK = (unsigned long long)(N2 - 1);
   __shared__ double s_wxy[N2];
   __shared__ double s_E[NG + 1];
   __shared__ double sIe[GROUPS][NG + 1];
   const int tid = threadIdx.x;
-  for (int m = tid; m < N2; m += OP_THREADS) s_wxy[m] = p.wxy[m];
-  if (tid <= NG) s_E[tid] = p.wbin_e[tid];
+  // ng <= NG g-points (round 3: 12 runs in the 16-lane kernel, 4 and 6 in the 8-lane one, 20-28 in the 32-lane one
+  // instead of the wave-per-item generic kernel): the lanes g >= ng of a group carry coefficients of PAD_K -- finite, far
+  // above any optical depth -- and pair weights of 0, so their sums sort behind the real ones, add nothing to the running
+  // weight or integral, and every output edge k <= ng is crossed inside the real data; they store nothing.
+  const int ng = p.ng;
+  constexpr double PAD_K = 1.0e290;
+  for (int m = tid; m < N2; m += OP_THREADS) {
+    const int gi = m / NG, ri = m % NG;
+    s_wxy[m] = (gi < ng && ri < ng) ? p.wxy[gi * ng + ri] : 0.0;
+  }
+  if (tid <= NG) s_E[tid] = tid <= ng ? p.wbin_e[tid] : __longlong_as_double(0x7ff0000000000000LL);
   __syncthreads();
   const ColumnDev &c = p.col;
   const int nz = p.nz;
   const int g = tid & (NG - 1), grp = tid / NG;
+  const bool g_on = g < ng;
   const int nsrc = c.meta[0];
   const long total = (long)p.nbins * nsrc;
   long t = ((long)blockIdx.x * OP_THREADS + tid) / NG;
@@ -1298,8 +1329,8 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
   const int j = ent & SRC_LAYER;
   const bool pair = (ent & SRC_PAIR) != 0, exact = (ent & SRC_EXACT) != 0;
   const int n = nz - 1 - j;
-  const double wg = p.wbin[g];
-  const double rWg = 1.0 / (s_E[g + 1] - s_E[g]);
+  const double wg = g_on ? p.wbin[g] : 0.0;
+  const double rWg = g_on ? 1.0 / (s_E[g + 1] - s_E[g]) : 0.0;
 
   // ---- layer terms (types.f90:665-757), shared out over the lanes of the group: lane g takes the
   //      Rayleigh species and continuum entries g, g+NG, ...; the partial sums meet in a butterfly
@@ -1362,11 +1393,13 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
     const int iP = c.ix[kd.slotP * nz + j], iT = c.ix[kd.slotT * nz + j];
     const double q1 = c.q[kd.slotP * nz + j], q2 = c.q[kd.slotT * nz + j];
     const double p1 = 1.0 - q1, p2 = 1.0 - q2;
-    const double *f11 = kd.log10k + (size_t)l * kd.nT * kd.nP * NG + ((size_t)iT * kd.nP + iP) * NG;
-    const double *f21 = f11 + NG, *f12 = f11 + (size_t)kd.nP * NG, *f22 = f12 + NG;
-    const double fx1 = p1 * f11[g] + q1 * f21[g];
-    const double fx2 = p1 * f12[g] + q1 * f22[g];
-    return ten2power(p2 * fx1 + q2 * fx2) * c.cols[kd.sp * nz + jl];
+    const double *f11 = kd.log10k + (size_t)l * kd.nT * kd.nP * ng + ((size_t)iT * kd.nP + iP) * ng;
+    const double *f21 = f11 + ng, *f12 = f11 + (size_t)kd.nP * ng, *f22 = f12 + ng;
+    const int gq = min(g, ng - 1);
+    const double fx1 = p1 * f11[gq] + q1 * f21[gq];
+    const double fx2 = p1 * f12[gq] + q1 * f22[gq];
+    const double kv = ten2power(p2 * fx1 + q2 * fx2) * c.cols[kd.sp * nz + jl];
+    return g_on ? kv : PAD_K;
   };
   LayerTerms lt;
   layer_terms(j, lt);
@@ -1405,12 +1438,12 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
     const double Cbase = Cs - Cw, ICbase = ICs - ICw;
     double hiC = __shfl_down(Cs - Cw, 1);  // the next lane's first running weight
     if (g == NG - 1) hiC = __longlong_as_double(0x7ff0000000000000LL);
-    if (g == NG - 1) sIe[grp][NG] = ICs;   // the last edge is the total weight
+    if (g == NG - 1) sIe[grp][ng] = ICs;   // the last edge is the total weight
     if (g == 0) sIe[grp][0] = 0.0;
     // the output edges crossed inside this lane's run of ranks: Cbase < E_k <= hiC
     int k = 1;
-    while (k < NG && s_E[k] <= Cbase) k++;
-    for (; k < NG; k++) {
+    while (k < ng && s_E[k] <= Cbase) k++;
+    for (; k < ng; k++) {
       const double Ek = s_E[k];
       if (!(Ek <= hiC)) break;
       double C = Cbase, IC = ICbase, I = -1.0e300;
@@ -1424,7 +1457,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the group's lanes are lanes of this wave
-    tk = (sIe[grp][g + 1] - sIe[grp][g]) * rWg;
+    tk = g_on ? (sIe[grp][g + 1] - sIe[grp][g]) * rWg : PAD_K;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the next mixing step rewrites the slots
   }
 
@@ -1434,9 +1467,9 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
     double w0;
     if (tau <= TAU_MIN) w0 = 0.0;
     else w0 = fmin(MAX_W0, (T.tausg + T.tausp + T.tausc) / tau);
-    const double tb = group_sum<NG>(tau * wg);
-    if (valid) {
-      const size_t o = ((size_t)l * NG + g) * nz + nn;
+    const double tb = group_sum<NG>(g_on ? tau * wg : 0.0);
+    if (valid && g_on) {
+      const size_t o = ((size_t)l * ng + g) * nz + nn;
       p.tau[o] = tau;
       p.w0[o] = w0;
       if (g == 0) {
@@ -1460,9 +1493,9 @@ __global__ __launch_bounds__(OP_THREADS) void k_opacity_coop(OpacityParams p) {
     double w0;
     if (tau <= TAU_MIN) w0 = 0.0;
     else w0 = fmin(MAX_W0, (lt2.tausg + lt2.tausp + lt2.tausc) / tau);
-    const double tb = group_sum<NG>(tau * wg);
-    if (keep) {
-      const size_t o = ((size_t)l * NG + g) * nz + (n - 1);
+    const double tb = group_sum<NG>(g_on ? tau * wg : 0.0);
+    if (keep && g_on) {
+      const size_t o = ((size_t)l * ng + g) * nz + (n - 1);
       p.tau[o] = tau;
       p.w0[o] = w0;
       if (g == 0) {
@@ -1483,9 +1516,12 @@ static void launch_coop(const OpacityParams &p, hipStream_t s) {
 
 bool launch_opacity(const OpacityParams &p, hipStream_t s) {
   long total = (long)p.nbins * p.nz;
-  if ((p.ng == 16 || p.ng == 32 || (p.ng == 8 && p.coop)) && (long)p.nbins * p.nsrc > 0) {
-    if (p.ng == 8) launch_coop<8>(p, s);
-    else if (p.ng == 16) launch_coop<16>(p, s);
+  // every g-point count but the tuned 8 goes to the group-of-lanes kernel with the next power of two of lanes per item
+  // (OpacityParams::generic, CLIMA_HIP_GENERIC=1 when the handle is made: the wave-per-item generic kernel instead --
+  // the same arithmetic order as the reference, kept as a cross-check)
+  if (p.ng >= 1 && p.ng <= 32 && (p.ng != 8 ? !p.generic : p.coop != 0) && (long)p.nbins * p.nsrc > 0) {
+    if (p.ng <= 8) launch_coop<8>(p, s);
+    else if (p.ng <= 16) launch_coop<16>(p, s);
     else launch_coop<32>(p, s);
     return true;
   }
@@ -2691,6 +2727,17 @@ __global__ __launch_bounds__(64 * TSW_COLS, LMAX > 4 ? 2 : 1) void k_twostream_w
   else twostream_p_body<LMAX, false, 0, false, false>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
 }
 
+// The half-wave form as a launch of its own (round 3): a wave solves two g-point columns, a block of 4 waves the 8
+// g-point columns of group blockIdx.y -- for k-distribution settings of 16, 24, 32 g-points (their calls take one
+// launch per kernel) at 65-224 layers: half as many blocks as the whole-wave kernel needs, each adding one addend per
+// level instead of two.  16 g-points: 98 -> ~55 us of two-stream launches per call.
+template <int L>
+__global__ __launch_bounds__(64 * TSW_COLS, 2) void k_twostream_h(TwoStreamParams p) {
+  extern __shared__ __align__(16) double lds[];  // [2 TSW_COLS][nz+1][3] weighted level values, then the Planck table
+  if ((int)blockIdx.x < p.n_sol) twostream_p_body<L, true, 0, false, false, false, true>(p, (int)blockIdx.x, lds, (int)blockIdx.y, (int)blockIdx.z);
+  else twostream_p_body<L, false, 0, false, false, false, true>(p, (int)blockIdx.x - p.n_sol, lds, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
   // partial sums over g-point groups accumulate into zeroed outputs: one launch
   const size_t nl = (size_t)p.nz + 1;
@@ -2722,6 +2769,26 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   if (grid <= 0) return true;
   if (groups > 1 && !zeroed) ts_zero_outputs(p, s);
   using Kern = void (*)(TwoStreamParams);
+  {
+    // 16, 24, 32 ... g-points at 65-224 layers: the half-wave kernel, 8 columns per block
+    static const bool off = [] { const char *e = getenv("CLIMA_HIP_NO_HALF"); return e && e[0] == '1'; }();
+    const int hs = (p.nz + 31) / 32;
+    if (!off && p.ng >= 16 && p.ng % 8 == 0 && hs >= 3 && hs <= 7 && p.force_slots == 0 && p.nzen <= MAX_ZEN) {
+      static const Kern kh[5] = {k_twostream_h<3>, k_twostream_h<4>, k_twostream_h<5>, k_twostream_h<6>, k_twostream_h<7>};
+      const size_t ldsh = sizeof(double) * (3 * 2 * TSW_COLS + 1) * ((size_t)p.nz + 1);
+      if (ldsh <= 64 * 1024 && (ldsh <= 48 * 1024 || ensure_max_lds((const void *)kh[hs - 3], 64 * 1024))) {
+        if (lds_bytes) *lds_bytes = ldsh;
+        const int g8 = p.ng / 8;
+        const int per = g8 <= 2 ? g8 : 1;   // two addends onto zero are order-independent; more go one launch at a time
+        for (int g0 = 0; g0 < g8; g0 += per) {
+          p.col_base = g0 * 2 * TSW_COLS;
+          p.accumulate = 1;
+          hipLaunchKernelGGL(kh[hs - 3], dim3(grid, per, p.b_ncol > 0 ? p.b_ncol : 1), dim3(64 * TSW_COLS), ldsh, s, p);
+        }
+        return true;
+      }
+    }
+  }
   static const Kern kern[8] = {k_twostream_w<1>, k_twostream_w<2>, k_twostream_w<3>, k_twostream_w<4>,
                                k_twostream_w<5>, k_twostream_w<6>, k_twostream_w<7>, k_twostream_w<8>};
   if (lds > 48 * 1024 && !ensure_max_lds((const void *)kern[lmax - 1], 64 * 1024)) return false;  // (static LDS on top)

@@ -216,6 +216,7 @@ struct Radtran {
   int rebin_mode = 1;              // 0 window form, 1 streaming, 2 streaming multi-edge (rebin_mode_for)
   long coop_items = 28672;         // ng = 8: at most this many (bin, source layer) items go to k_opacity_coop<8> (CLIMA_HIP_COOP_ITEMS)
   bool fused = true;               // opacity + two-stream in one grid (k_fused); CLIMA_HIP_FUSED=0 or radtran_fused_set turns it off
+  bool generic_opacity = false;    // g-point counts other than 8: k_opacity_generic instead of the group-of-lanes kernel (CLIMA_HIP_GENERIC=1)
   DevBuf<int> d_done;              // per opacity block: call id of its last completed run
   int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (id 1) only
   long timer_calls = 0;
@@ -688,6 +689,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     // few (bin, source layer) items -- a bin-sharded rank, a short or all-pairs column: the group-of-lanes
     // kernel (a fifth of the lane-per-item kernel's dependent chain) and one launch per kernel
     op.coop = (!bc && r->ng == 8 && (long)r->op_n * nsrc <= r->coop_items) ? 1 : 0;
+    op.generic = r->generic_opacity ? 1 : 0;
 #ifdef CLIMA_STAMPS
     op.stamps = r->d_stamps.p;
 #endif
@@ -1278,6 +1280,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&r->ev_upload, hipEventDisableTiming));
   if (const char *f = getenv("CLIMA_HIP_FUSED")) r->fused = atoi(f) != 0;
+  if (const char *f = getenv("CLIMA_HIP_GENERIC")) r->generic_opacity = atoi(f) != 0;
   if (const char *f = getenv("CLIMA_HIP_BATCH_SHARED")) r->batch_shared = atoi(f) != 0;
   if (const char *f = getenv("CLIMA_HIP_FUSED_SPINS")) r->fused_max_spins = std::max(0, atoi(f));  // test aid: 0 makes waits expire
 

@@ -128,6 +128,7 @@ struct OpacityParams {
   int bin_lo, nbins;  // opacity bins handled by this launch
   int nsrc;           // source layers of the column (host count, == meta[0]); nz for a batch (upper bound)
   int coop;           // ng = 8: use the group-of-lanes kernel (k_opacity_coop<8>) -- few items, latency matters
+  int generic;        // ng != 8: the wave-per-item generic kernel instead of the group-of-lanes one (cross-check)
   int nk, nray, npart;
   KDev k[MAX_K];
   XsDev ray[MAX_XS];

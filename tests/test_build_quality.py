@@ -19,7 +19,7 @@ from clima_amd import build as B
 
 # kernels of the production paths: fused grid, stand-alone opacity tile, group-of-lanes opacity,
 # wave-per-column two-stream, batched IR, prep, integration
-HOT = re.compile(r"k_fused|k_opacity8|k_opacity_coop|k_twostream_w|k_twostream_ir_batch|k_prep|k_integrate_one")
+HOT = re.compile(r"k_fused|k_opacity8|k_opacity_coop|k_twostream_w|k_twostream_h|k_twostream_ir_batch|k_prep|k_integrate_one")
 
 
 @pytest.fixture(scope="module")
@@ -44,11 +44,20 @@ def assembly():
     return kernels
 
 
+# The 16- and 32-lane group-of-lanes kernels are compiled for one wave per SIMD more than their registers allow
+# without spilling (round 3, measured: 610 -> 541 us at 16 g-points, 4.67 -> 2.92 ms at 32): a few dozen scratch accesses
+# outside the sort network are the price, and are bounded here.
+BOUNDED = re.compile(r"k_opacity_coopILi(16|32)E")
+BOUND = 64
+
+
 def test_hot_kernels_have_no_scratch_traffic(assembly):
     hot = {k: v for k, v in assembly.items() if HOT.search(k)}
     assert len(hot) >= 30, sorted(hot)             # every instantiation of the fused grid and the stand-alone kernels
-    bad = {k: v for k, v in hot.items() if v}
+    bad = {k: v for k, v in hot.items() if v and not BOUNDED.search(k)}
     assert not bad, "scratch instructions in: %s (python tools/scratch_report.py)" % bad
+    over = {k: v for k, v in hot.items() if BOUNDED.search(k) and v > BOUND}
+    assert not over, "more than %d scratch instructions in: %s" % (BOUND, over)
 
 
 def test_build_flags_keep_parameter_blocks_in_the_kernarg_segment():

@@ -282,13 +282,19 @@ def test_uneven_g_weights_multi_edge_rebin(O):
     _compare(r, o, S.modern_earth_column(33))
 
 
-@pytest.mark.parametrize("ng,sorted_k", [(4, True), (6, True), (12, False), (16, True), (32, True)])
-def test_other_g_point_counts_generic_kernel(O, ng, sorted_k):
-    # `new_num_k_bins` need not be 8: the generic resort-rebin kernel (wave per (bin, layer),
-    # bitonic sort on (value, index) in LDS) and the per-group two-stream launches
+@pytest.mark.parametrize("generic", [0, 1])
+@pytest.mark.parametrize("ng,sorted_k", [(1, True), (4, True), (6, True), (12, False), (12, True), (16, True), (20, True), (24, False),
+                                         (32, True)])
+def test_other_g_point_counts(O, ng, sorted_k, generic, monkeypatch):
+    # `new_num_k_bins` need not be 8.  generic = 0: the group-of-lanes kernel with the next power of two of lanes per
+    # item, the lanes beyond ng padded (round 3: 12 g-points 4.2 ms -> 0.66 ms at config 2's size); generic = 1
+    # (CLIMA_HIP_GENERIC): the wave-per-item resort-rebin kernel (bitonic sort on (value, index) in LDS, the
+    # reference's arithmetic order) kept as a cross-check.  Both with the per-group two-stream launches.
     from clima_amd import synthetic as S
     tb = S.modern_earth_tables(nw=12, ng=ng, sorted_k=sorted_k, seed=5 + ng)
+    monkeypatch.setenv("CLIMA_HIP_GENERIC", str(generic))
     r, o = _pair(O, tb, 22, 2, 0.25)
+    monkeypatch.delenv("CLIMA_HIP_GENERIC")
     _compare(r, o, S.doubled_column(S.modern_earth_column(11)))
 
 
@@ -839,3 +845,21 @@ def test_batched_shared_opacity_ir_calls_at_other_g_point_counts(O, ng, nz):
         assert _scaled(fup[:, c], o.wrk_ir.fup_n) <= TOL_LEVEL
         assert _scaled(fdn[:, c], o.wrk_ir.fdn_n) <= TOL_LEVEL
         assert _scaled(ftot[:, c], o.f_total) <= TOL_LEVEL
+
+
+@pytest.mark.parametrize("ng,nz", [(16, 100), (16, 200), (24, 70), (32, 130), (32, 224)])
+def test_half_wave_two_stream_launch_at_16_24_32_g_points(O, ng, nz):
+    """k_twostream_h<L>: the half-wave two-stream form as a launch of its own (8 g-point columns per block, one or two
+    groups of 8 per launch), what calls with 16 / 24 / 32 g-points at 65-224 layers run (CLIMA_HIP_NO_HALF=1 selects
+    the whole-wave kernel it replaces): against the oracle, and repeatable bit for bit."""
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    tb = S.modern_earth_tables(nw=10, ng=ng, seed=60 + ng)
+    col = S.modern_earth_column(nz)
+    r, o = _pair(O, tb, nz, 3, 0.2)
+    _compare_once(r, o, col)
+    half_up, half_ft = np.array(r.wrk_sol.fup_n), np.array(r.f_total)
+    r2 = Radtran(tb, nz, 3, 0.2)
+    r2.radiate(*col.args())
+    np.testing.assert_array_equal(np.array(r2.f_total), half_ft)            # repeatable bit for bit (atomics of two addends)
+    np.testing.assert_array_equal(np.array(r2.wrk_sol.fup_n), half_up)
