@@ -1401,9 +1401,6 @@ __global__ __launch_bounds__(OP_THREADS, COOP_MIN_BLOCKS(NG)) void k_opacity_coo
     const double kv = ten2power(p2 * fx1 + q2 * fx2) * c.cols[kd.sp * nz + jl];
     return g_on ? kv : PAD_K;
   };
-  LayerTerms lt;
-  layer_terms(j, lt);
-
   const int gbase = (tid & 63) & ~(NG - 1);  // first lane of the group within the wave
   double tk = k_times_col(0, j);
   for (int s = 1; s < p.nk; s++) {
@@ -1460,6 +1457,11 @@ __global__ __launch_bounds__(OP_THREADS, COOP_MIN_BLOCKS(NG)) void k_opacity_coo
     tk = g_on ? (sIe[grp][g + 1] - sIe[grp][g]) * rWg : PAD_K;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the next mixing step rewrites the slots
   }
+
+  // the layer's other terms are needed by the totals only: evaluated here, they do not sit in registers through the
+  // mixing steps
+  LayerTerms lt;
+  layer_terms(j, lt);
 
   // ---- totals (:856-886)
   auto store_layer = [&](const int nn, const LayerTerms &T, const double tkv) {
