@@ -319,6 +319,22 @@ __device__ __forceinline__ double planck_fcn(double nu, double T) {
          ((1.0) / (fast_exp((PLANK * nu) / (K_BOLTZ_SI * T)) - 1.0));
 }
 
+// A double moved between lanes by DPP (data-parallel primitives: the operand routing of a VALU move, a few cycles)
+// instead of a ds_bpermute round trip through the LDS crossbar (~100+).  Lanes without a source keep `old`.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov(double old, double src) {
+  const long long o = __double_as_longlong(old), v = __double_as_longlong(src);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(v >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+// x of lane - D / lane + D within the 16-lane row (D = 1..15); `old` where the row has no such lane
+template <int D>
+__device__ __forceinline__ double row_shr(double old, double x) { return dpp_mov<DPP_ROW_SHR + D, 0xf, 0xf>(old, x); }
+template <int D>
+__device__ __forceinline__ double row_shl(double old, double x) { return dpp_mov<DPP_ROW_SHL + D, 0xf, 0xf>(old, x); }
+
 // futils is_close (fortran-stdlib form): |a-b| <= tol*max(|a|,|b|)
 __device__ __forceinline__ bool is_close(double a, double b, double tol) {
   return fabs(a - b) <= fabs(tol * fmax(fabs(a), fabs(b)));
@@ -1415,7 +1431,9 @@ __global__ __launch_bounds__(OP_THREADS, COOP_MIN_BLOCKS(NG)) void k_opacity_coo
       key[r] = __longlong_as_double((long long)b);
     }
     // rows ascend when y does; otherwise sort within the lanes first
-    const double kc_next = __shfl_down(kc, 1);
+    double kc_next;
+    if constexpr (NG <= 16) kc_next = row_shl<1>(kc, kc);   // (lane 15 of a row keeps its own: it is a group's last lane)
+    else kc_next = __shfl_down(kc, 1);
     const bool ys = __all(g == NG - 1 || kc <= kc_next);
     if (!ys) CoopSort<NG>::template levels<2, NG>(key, g);
     CoopSort<NG>::template levels<2 * NG, N2>(key, g);
@@ -1426,14 +1444,24 @@ __global__ __launch_bounds__(OP_THREADS, COOP_MIN_BLOCKS(NG)) void k_opacity_coo
     double Cw = 0.0, ICw = 0.0;
 #pragma unroll
     for (int r = 0; r < NG; r++) { ICw = __builtin_fma(key[r], w[r], ICw); Cw = Cw + w[r]; }
-    double Cs = Cw, ICs = ICw;  // inclusive scan over the lanes of the group
-#pragma unroll
-    for (int d = 1; d < NG; d <<= 1) {
-      const double a = __shfl_up(Cs, d), b2 = __shfl_up(ICs, d);
-      if (g >= d) { Cs = Cs + a; ICs = ICs + b2; }
+    double Cs = Cw, ICs = ICw;  // inclusive scan over the lanes of the group: DPP shifts within the 16-lane row (a
+                                // group is half a row, a row, or two rows: the second row of NG = 32 then adds the
+                                // first row's total, fetched over the crossbar)
+    auto scan_step = [&](const double a, const double b2, const int d) {
+      if ((g & 15) >= d) { Cs = Cs + a; ICs = ICs + b2; }
+    };
+    scan_step(row_shr<1>(0.0, Cs), row_shr<1>(0.0, ICs), 1);
+    scan_step(row_shr<2>(0.0, Cs), row_shr<2>(0.0, ICs), 2);
+    scan_step(row_shr<4>(0.0, Cs), row_shr<4>(0.0, ICs), 4);
+    if constexpr (NG >= 16) scan_step(row_shr<8>(0.0, Cs), row_shr<8>(0.0, ICs), 8);
+    if constexpr (NG >= 32) {
+      const double c15 = __shfl(Cs, gbase + 15), ic15 = __shfl(ICs, gbase + 15);
+      if (g >= 16) { Cs = Cs + c15; ICs = ICs + ic15; }
     }
     const double Cbase = Cs - Cw, ICbase = ICs - ICw;
-    double hiC = __shfl_down(Cs - Cw, 1);  // the next lane's first running weight
+    double hiC;   // the next lane's first running weight
+    if constexpr (NG <= 16) hiC = row_shl<1>(0.0, Cbase);
+    else hiC = __shfl_down(Cbase, 1);
     if (g == NG - 1) hiC = __longlong_as_double(0x7ff0000000000000LL);
     if (g == NG - 1) sIe[grp][ng] = ICs;   // the last edge is the total weight
     if (g == 0) sIe[grp][0] = 0.0;
@@ -2106,14 +2134,6 @@ bool launch_twostream(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes) {
 // A lane with no source in a step keeps `old`: 0 for an a-part, 1 for a b-part, which makes the
 // step the identity for it -- no participation masks needed.
 // ------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ double dpp_mov(double old, double src) {
-  const long long o = __double_as_longlong(old), v = __double_as_longlong(src);
-  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
-  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(v >> 32), CTRL, ROW_MASK, BANK_MASK, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 constexpr int WSCAN_STEPS = 7;
 
 // value a step brings in from the lower lane(s); `orig` is the value before the scan (steps 0-2
