@@ -8,12 +8,15 @@
 //                      random-overlap resort-rebin (types.f90:640-888); the 64-key resort is a register-resident
 //                      Batcher network (v_min_f64 / v_max_f64), the rebin the "window" form.
 //   k_opacity_coop     NG = 8, 16 or 32 lanes per (bin, source layer): the sort across the group (DPP / ds_swizzle);
-//                      few-item calls (a bin-sharded rank) and the 16- / 32-g-point settings.
-//   k_opacity_generic  any other g-point count 1..32 (one wave per item, LDS bitonic sort): completeness path.
+//                      few-item calls (a bin-sharded rank) and EVERY g-point count other than 8 (1..32: the lanes
+//                      beyond ng are padded).
+//   k_opacity_generic  any g-point count 1..32, one wave per item, LDS bitonic sort in the reference's arithmetic
+//                      order: a cross-check (CLIMA_HIP_GENERIC=1), on no default path.
 //   k_twostream_w      one WAVE per (channel, bin, g-point) -- twostream_p_body: lane q owns a chunk of layers in
 //                      registers, per-lane elimination with flux boundary conditions, the chunks joined by DPP wave
 //                      scans (3x3 projective suffix scan + affine prefix scan); half-wave (two columns per wave) and
 //                      paired (AdiabatClimate's doubled grid) forms (radiate.f90:50-158, twostream.f90:10-295).
+//   k_twostream_h      the half-wave form of twostream_p_body as a launch of its own (16 / 24 / 32 g-points).
 //   k_twostream        one WORKGROUP per (channel, bin), LDS image + 16-chunk decomposition: beyond 512 layers.
 //   k_twostream_ir_batch  many temperature columns on one set of opacities (the RCE Jacobian,
 //                      src/adiabat/clima_adiabat_solve.f90:798-812): the temperature-independent part once per
@@ -2780,6 +2783,21 @@ static void ts_zero_outputs(const TwoStreamParams &p, hipStream_t s) {
 // wave-per-column launcher; false when nz needs more than 8 layers per lane
 int twostream_w_groups(int ng) { return (ng + TSW_COLS - 1) / TSW_COLS; }
 
+// slots per lane (3..7) when launch_twostream_w() will take the half-wave kernel k_twostream_h for this call, else 0.
+// With 8 g-points that kernel stores every output value itself: the caller need not clear the outputs first.
+int twostream_w_half_slots(const TwoStreamParams &p) {
+  static const bool off = [] { const char *e = getenv("CLIMA_HIP_NO_HALF"); return e && e[0] == '1'; }();
+  const int hs = (p.nz + 31) / 32;
+  if (off || p.ng < 8 || p.ng % 8 != 0 || hs < 3 || hs > 7 || p.force_slots != 0 || p.nzen > MAX_ZEN) return 0;
+  if (sizeof(double) * (3 * 2 * TSW_COLS + 1) * ((size_t)p.nz + 1) > 64 * 1024) return 0;
+  // 8 g-points: its blocks are half as many and nearly twice as long as the whole-wave kernel's, which pays when the
+  // launch is throughput-bound or when it saves the clearing launch -- IR-only calls on stored opacities (102 / 202
+  // layers: 19.3 -> 16.7, 26.1 -> 22.3 us per call) -- and loses when a few bins' blocks are the whole launch (a rank's
+  // share of 8: 12.9 -> 15.2 us); profiles/r03_coop_ab.txt
+  if (p.ng == 8 && p.n_sol > 0 && p.n_sol + p.n_ir < 512) return 0;
+  return hs;
+}
+
 bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bool zeroed) {
   const int lmax = std::max((p.nz + 63) / 64, p.force_slots);
   if (lmax > 8) return false;
@@ -2789,28 +2807,27 @@ bool launch_twostream_w(TwoStreamParams &p, hipStream_t s, size_t *lds_bytes, bo
   if (lds > 64 * 1024) return false;
   const int grid = p.n_sol + p.n_ir;
   if (grid <= 0) return true;
-  if (groups > 1 && !zeroed) ts_zero_outputs(p, s);
   using Kern = void (*)(TwoStreamParams);
-  {
-    // 16, 24, 32 ... g-points at 65-224 layers: the half-wave kernel, 8 columns per block
-    static const bool off = [] { const char *e = getenv("CLIMA_HIP_NO_HALF"); return e && e[0] == '1'; }();
-    const int hs = (p.nz + 31) / 32;
-    if (!off && p.ng >= 16 && p.ng % 8 == 0 && hs >= 3 && hs <= 7 && p.force_slots == 0 && p.nzen <= MAX_ZEN) {
-      static const Kern kh[5] = {k_twostream_h<3>, k_twostream_h<4>, k_twostream_h<5>, k_twostream_h<6>, k_twostream_h<7>};
-      const size_t ldsh = sizeof(double) * (3 * 2 * TSW_COLS + 1) * ((size_t)p.nz + 1);
-      if (ldsh <= 64 * 1024 && (ldsh <= 48 * 1024 || ensure_max_lds((const void *)kh[hs - 3], 64 * 1024))) {
-        if (lds_bytes) *lds_bytes = ldsh;
-        const int g8 = p.ng / 8;
-        const int per = g8 <= 2 ? g8 : 1;   // two addends onto zero are order-independent; more go one launch at a time
-        for (int g0 = 0; g0 < g8; g0 += per) {
-          p.col_base = g0 * 2 * TSW_COLS;
-          p.accumulate = 1;
-          hipLaunchKernelGGL(kh[hs - 3], dim3(grid, per, p.b_ncol > 0 ? p.b_ncol : 1), dim3(64 * TSW_COLS), ldsh, s, p);
-        }
-        return true;
+  if (const int hs = twostream_w_half_slots(p)) {
+    // 8, 16, 24, 32 g-points at 65-224 layers: the half-wave kernel, 8 columns per block.  With 8 g-points a block holds
+    // its bin's whole g-point sum and stores it: nothing to clear first, no adds (IR-only calls on stored opacities,
+    // few-item calls: one launch and ~1/5 of the instructions fewer than the whole-wave kernel with its two groups)
+    static const Kern kh[5] = {k_twostream_h<3>, k_twostream_h<4>, k_twostream_h<5>, k_twostream_h<6>, k_twostream_h<7>};
+    const size_t ldsh = sizeof(double) * (3 * 2 * TSW_COLS + 1) * ((size_t)p.nz + 1);
+    if (ldsh <= 48 * 1024 || ensure_max_lds((const void *)kh[hs - 3], 64 * 1024)) {
+      if (lds_bytes) *lds_bytes = ldsh;
+      const int g8 = p.ng / 8;
+      if (g8 > 1 && !zeroed) ts_zero_outputs(p, s);
+      const int per = g8 <= 2 ? g8 : 1;   // two addends onto zero are order-independent; more go one launch at a time
+      for (int g0 = 0; g0 < g8; g0 += per) {
+        p.col_base = g0 * 2 * TSW_COLS;
+        p.accumulate = g8 > 1 ? 1 : 0;
+        hipLaunchKernelGGL(kh[hs - 3], dim3(grid, per, p.b_ncol > 0 ? p.b_ncol : 1), dim3(64 * TSW_COLS), ldsh, s, p);
       }
+      return true;
     }
   }
+  if (groups > 1 && !zeroed) ts_zero_outputs(p, s);
   static const Kern kern[8] = {k_twostream_w<1>, k_twostream_w<2>, k_twostream_w<3>, k_twostream_w<4>,
                                k_twostream_w<5>, k_twostream_w<6>, k_twostream_w<7>, k_twostream_w<8>};
   if (lds > 48 * 1024 && !ensure_max_lds((const void *)kern[lmax - 1], 64 * 1024)) return false;  // (static LDS on top)

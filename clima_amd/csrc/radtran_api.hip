@@ -651,6 +651,10 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
         if ((bc || (r->fused && allow_fused && !coop)) && wave_mode && twostream_w_groups(r->ng) >= 2) {
           const TwoStreamParams tq = ts_params();
           whole_stores = fused_half_form(oq, tq, ncol) != 0;
+        } else if (!bc && wave_mode && r->ng == 8) {
+          // one launch per kernel: the stand-alone half-wave two-stream kernel stores whole values too
+          const TwoStreamParams tq = ts_params();
+          whole_stores = tq.nzen <= MAX_ZEN && twostream_w_half_slots(tq) != 0;
         }
       }
       if (wave_mode && twostream_w_groups(r->ng) >= 2 && !whole_stores) {

@@ -271,6 +271,7 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
 // (meta_nsrc: a device int, any value >= 1)
 bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta_nsrc, hipStream_t s, bool half = false, bool paired = false);
 int twostream_w_groups(int ng);
+int twostream_w_half_slots(const TwoStreamParams &p);   // > 0: launch_twostream_w takes k_twostream_h (with 8 g-points: stores whole values)
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
 void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t s);
 int integrate_chunks(int nbins);
