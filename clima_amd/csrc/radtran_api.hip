@@ -1746,10 +1746,15 @@ void radtran_apply_radiation_enhancement(void *ptr, const double *rad_enhancemen
   if (!r || r->state != 2) return;
   try {  // clima_radtran.f90:402-411
     const int nl = r->nz + 1;
+    settle(r);   // the results being scaled are final (a hand-off that timed out has been repaired BEFORE, not after)
     launch_scale(r->wrk_sol.fdn_a.p, r->wrk_sol.fdn_a.n, *rad_enhancement, r->stream);
     launch_scale(r->wrk_sol.fup_a.p, r->wrk_sol.fup_a.n, *rad_enhancement, r->stream);
     launch_scale(r->d_flux_n.p + 2 * nl, (size_t)2 * nl, *rad_enhancement, r->stream);
-    launch_f_total(r->nz, r->d_flux_n.p, r->d_f_total.p, r->stream);
+    // a bin-sharded handle keeps its PARTIAL solar rows for the IR-only steps that follow: they are scaled too
+    if (r->shard_world > 1 && r->d_flux_part.p) launch_scale(r->d_flux_part.p + 2 * nl, (size_t)2 * nl, *rad_enhancement, r->stream);
+    // (with a communicator the slot behind the rows carries the step's status word, and f_total is formed on the host
+    // from the rows in any case: fetch_small)
+    if (!r->comm) launch_f_total(r->nz, r->d_flux_n.p, r->d_f_total.p, r->stream);
     r->small_valid = false;
     fetch_small(r);
     for (int i = 0; i < nl; i++) r->f_total[i] = r->h_small[4 * nl + i];

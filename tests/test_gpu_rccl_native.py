@@ -159,3 +159,40 @@ def test_fortran_driver_in_sharded_mode(hip_lib, tmp_path):
     n = 2 + 3 * (nz + 1) + nw_ir + nw_sol                          # ISR, OLR, three level rows, the two TOA spectra
     assert len(b) == n
     np.testing.assert_array_equal(a[:n], b)
+
+
+def test_radiation_enhancement_on_a_communicator_handle(hip_lib, small_tables):
+    """Radtran%apply_radiation_enhancement (clima_radtran.f90:402-411) on a handle whose level rows are reduced in
+    place: the slot behind the rows is the step's status word there, not f_total -- the scaling must neither disturb it
+    nor be undone by a repair that runs afterwards; IR-only steps that follow keep the enhanced solar rows."""
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    nz = 70
+    col = S.modern_earth_column(nz)
+    ref = Radtran(small_tables, nz, 2, 0.2)
+    ref.radiate(*col.args())
+    ref.apply_radiation_enhancement(1.6)
+    want_sol, want_f = np.array(ref.wrk_sol.fdn_n), np.array(ref.f_total)
+    parts = []
+    for k in range(2):
+        r = Radtran(small_tables, nz, 2, 0.2)
+        r.comm_init_rank(1, 0, Radtran.comm_unique_id())
+        r.set_bin_shard(k, 2)
+        r.upload_column(*col.args())
+        r.radiate_resident()                       # not synchronised: the enhancement settles the step itself
+        r.apply_radiation_enhancement(1.6)
+        assert r.fused_fallbacks == 0
+        parts.append(r)
+    got_sol = sum(np.array(p.wrk_sol.fdn_n) for p in parts)
+    np.testing.assert_allclose(got_sol, want_sol, rtol=1e-13)
+    got_f = sum(np.array(p.f_total) for p in parts)
+    np.testing.assert_allclose(got_f, want_f, rtol=1e-12, atol=1e-12 * np.max(np.abs(want_f)))
+    warm = S.Column(col)
+    warm["T"] = col["T"] + 1.0
+    ref.radiate(*warm.args(), compute_solar=False, compute_opacity=False)
+    for p in parts:
+        p.radiate(*warm.args(), compute_solar=False, compute_opacity=False)
+    got_sol = sum(np.array(p.wrk_sol.fdn_n) for p in parts)
+    np.testing.assert_allclose(got_sol, want_sol, rtol=1e-13)      # the enhanced partial rows were put back
+    got_f = sum(np.array(p.f_total) for p in parts)
+    np.testing.assert_allclose(got_f, np.array(ref.f_total), rtol=1e-12, atol=1e-12 * np.max(np.abs(want_f)))
