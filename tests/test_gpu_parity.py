@@ -538,7 +538,7 @@ def test_state_carried_between_calls(O, small_tables):
 
 
 @pytest.mark.parametrize("nz,ncol", [(50, 7), (30, 70), (300, 5), (1, 3), (64, 9), (65, 9), (100, 5), (150, 9), (193, 4), (256, 3),
-                                     (257, 4), (320, 9), (402, 11), (448, 3), (500, 6), (512, 3)])
+                                     (257, 4), (320, 9), (402, 11), (448, 3), (500, 6), (512, 3), (20, 600)])   # 600 columns: two launches of <= 512
 def test_batched_shared_opacity_ir_calls(O, small_tables, nz, ncol, monkeypatch):
     # the RCE Jacobian's loop (clima_adiabat_solve.f90:798-812) in one call: every column equals
     # radiate(..., compute_solar=False, compute_opacity=False) on the same resident opacities
