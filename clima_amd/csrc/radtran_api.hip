@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>   // the bin-sharded step's one collective; backend "nccl" on ROCm IS RCCL
 #include <sys/stat.h>
 #include <unistd.h>
+#include <ctime>
 
 #include <algorithm>
 #include <cmath>
@@ -1863,9 +1864,11 @@ void radtran_comm_init_file(void *ptr, const int *nranks, const int *rank, const
       throw HipFail{"radtran_comm_init_file: cannot write " + file};
   } else {
     bool got = false;
+    const time_t t_enter = time(nullptr);
     for (int tries = 0; tries < 6000 && !got; tries++) {   // up to ~120 s
       struct stat st;
-      if (stat(file.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(id)) {
+      // (a file much older than this call is a crashed job's leftover, not this job's id: keep waiting for rank 0)
+      if (stat(file.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(id) && st.st_mtime >= t_enter - 600) {
         FILE *f = std::fopen(file.c_str(), "rb");
         got = f && std::fread(id, 1, sizeof(id), f) == sizeof(id);
         if (f) std::fclose(f);

@@ -158,7 +158,7 @@ void radtran_comm_unique_id(char *id /* [CLIMA_COMM_ID_BYTES] */, char *err);
 /* collective over the nranks processes; also restricts the handle to the bins of shard (rank, nranks) */
 void radtran_comm_init_rank(void *ptr, const int *nranks, const int *rank, const char *id, char *err);
 /* the same with the id exchanged through a file that rank 0 creates (hosts without a message layer);
- * `path` (NUL-terminated) must be new for every job */
+ * `path` (NUL-terminated) must be new for every job (a file older than ten minutes is taken for a leftover and ignored) */
 void radtran_comm_init_file(void *ptr, const int *nranks, const int *rank, const char *path, char *err);
 /* nranks (0: no communicator), rank, all-reduces enqueued so far */
 void radtran_comm_get(void *ptr, int *nranks, int *rank, int *reduces);
