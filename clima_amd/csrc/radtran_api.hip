@@ -71,7 +71,7 @@ struct DevBuf {
     if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
   }
   void upload(const std::vector<T> &v) {
-    alloc(v.size());
+    if (!(p && owned && n == v.size())) alloc(v.size());   // (same size: the allocation is kept)
     if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   }
   void zero(hipStream_t s = nullptr) {
@@ -316,6 +316,8 @@ bool make_channel(Radtran *r, ChannelObj &c, int which, int n, const double *wav
 
 void upload_fields(Radtran *r) {
   if (!r->fields_dirty) return;
+  // kernels of earlier, unsynchronised calls may still be reading the old values
+  if (r->stream) HIPCHK(hipStreamSynchronize(r->stream));
   r->d_zen_u.upload(r->zenith_u);
   r->d_zen_w.upload(r->zenith_w);
   {
@@ -2231,8 +2233,10 @@ void radtran_equilibrium_temperature_wrapper(void *ptr, const double *bond_albed
   void radtran_##name##_set(void *ptr, const int *dim1, const double *arr) {                    \
     Radtran *r = as_rad(ptr);                                                                   \
     if (!r) return;                                                                             \
-    for (int i = 0; i < *dim1 && i < (int)r->field.size(); i++) r->field[i] = arr[i];           \
-    r->fields_dirty = true;                                                                     \
+    /* dirty only when a value changes: the Fortran module pushes every public field before every radiate, \
+       and an upload costs a stream synchronise and six copies */                                \
+    for (int i = 0; i < *dim1 && i < (int)r->field.size(); i++)                                 \
+      if (r->field[i] != arr[i]) { r->field[i] = arr[i]; r->fields_dirty = true; }              \
   }
 VEC_GETSET(zenith_u, zenith_u)
 VEC_GETSET(surface_albedo, surface_albedo)
@@ -2246,8 +2250,8 @@ void radtran_zenith_weights_get(void *ptr, const int *dim1, double *arr) {
 void radtran_zenith_weights_set(void *ptr, const int *dim1, const double *arr) {
   Radtran *r = as_rad(ptr);
   if (!r) return;
-  for (int i = 0; i < *dim1 && i < (int)r->zenith_w.size(); i++) r->zenith_w[i] = arr[i];
-  r->fields_dirty = true;
+  for (int i = 0; i < *dim1 && i < (int)r->zenith_w.size(); i++)
+    if (r->zenith_w[i] != arr[i]) { r->zenith_w[i] = arr[i]; r->fields_dirty = true; }
 }
 // logical(c_bool) in the reference (clima/fortran/Radtran.f90:211-227; Radtran_pxd.pxd:45-46 binds bool*):
 // exactly one byte is read or written

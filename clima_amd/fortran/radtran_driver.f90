@@ -102,6 +102,18 @@ program radtran_driver
   endif
   close(u)
 
+  ! timing mode: `radtran_driver case.bin out.txt time [ncalls]` -- the synchronous drop-in call as a Fortran host sees it
+  ! (SURVEY.md 8(d) "Metric": host arrays in, ISR / OLR out, device-synchronised), median of ncalls, with and without
+  ! the per-bin spectra copied back into rad%wrk_*%fup_a ... after every call (rad%sync_spectra)
+  if (command_argument_count() >= 3 .and. .not. sharded) then
+    call get_command_argument(3, arg)
+    if (trim(arg) == 'time') then
+      call time_calls()
+      call rad%destroy()
+      stop
+    endif
+  endif
+
   ! tests/test_radtran.f90:67
   if (np > 0) then
     call rad%radiate(T_surface, T, P, densities, dz, pdensities, radii, err=err)
@@ -197,6 +209,51 @@ program radtran_driver
   call rad%destroy()
 
 contains
+  subroutine time_calls()
+    use iso_fortran_env, only: int64
+    integer :: ncalls, k, pass
+    integer(int64) :: c0, c1, rate
+    real(dp), allocatable :: us(:)
+    real(dp) :: tmp
+    integer :: a, b
+    ncalls = 200
+    if (command_argument_count() >= 4) then
+      call get_command_argument(4, arg); read(arg, *) ncalls
+    endif
+    allocate(us(ncalls))
+    call system_clock(count_rate=rate)
+    do pass = 1, 2
+      rad%sync_spectra = pass == 2
+      do k = 1, 10 + ncalls
+        call system_clock(c0)
+        if (np > 0) then
+          call rad%TOA_fluxes(T_surface, T, P, densities, dz, pdensities, radii, ISR=ISR, OLR=OLR, err=err)
+        else
+          call rad%TOA_fluxes(T_surface, T, P, densities, dz, ISR=ISR, OLR=OLR, err=err)
+        endif
+        call system_clock(c1)
+        call check()
+        if (k > 10) us(k-10) = 1.0e6_dp*real(c1 - c0, dp)/real(rate, dp)
+      enddo
+      do a = 2, ncalls        ! insertion sort: the median
+        tmp = us(a); b = a - 1
+        do while (b >= 1)
+          if (us(b) <= tmp) exit
+          us(b+1) = us(b); b = b - 1
+        enddo
+        us(b+1) = tmp
+      enddo
+      if (pass == 1) then
+        write(output_unit,'(a,i0,a,f8.1,a,f8.1,a,f8.1,a)') 'fortran host, rad%TOA_fluxes x ', ncalls, &
+          ' (level fluxes only): median ', us((ncalls+1)/2), ' us  p10 ', us(max(1,ncalls/10)), '  p90 ', us(max(1,(9*ncalls)/10)), ' us'
+      else
+        write(output_unit,'(a,i0,a,f8.1,a)') 'fortran host, rad%TOA_fluxes x ', ncalls, &
+          ' (+ every per-bin spectrum copied back, rad%sync_spectra = .true.): median ', us((ncalls+1)/2), ' us'
+      endif
+    enddo
+    write(output_unit,'(a,2es24.15)') 'ISR, OLR (mW/m^2): ', ISR, OLR
+  end subroutine
+
   subroutine check()
     if (allocated(err)) then
       print*, err
