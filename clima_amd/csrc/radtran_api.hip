@@ -218,6 +218,8 @@ struct Radtran {
   long coop_items = 28672;         // ng = 8: at most this many (bin, source layer) items go to k_opacity_coop<8> (CLIMA_HIP_COOP_ITEMS)
   bool fused = true;               // opacity + two-stream in one grid (k_fused); CLIMA_HIP_FUSED=0 or radtran_fused_set turns it off
   bool generic_opacity = false;    // g-point counts other than 8: k_opacity_generic instead of the group-of-lanes kernel (CLIMA_HIP_GENERIC=1)
+  bool ts_block_mode = false;      // CLIMA_HIP_TS_MODE=block when the handle was made: the workgroup-per-bin two-stream kernel
+  int ts_ncols_env = 0;            // CLIMA_HIP_TS_NCOLS (that kernel's columns per block), 0: its own choice
   DevBuf<int> d_done;              // per opacity block: call id of its last completed run
   int profile = 0;   // 0 off, 1 HIP events around every kernel, 2 around the dominant kernel (id 1) only
   long timer_calls = 0;
@@ -542,7 +544,8 @@ TwoStreamParams make_twostream_params(Radtran *r, const ColumnDev &col, bool com
   const int nz = r->nz;
   std::memset(&ts, 0, sizeof(ts));
   ts.nz = nz; ts.ng = r->ng;
-  if (const char *nc = getenv("CLIMA_HIP_TS_NCOLS")) ts.ncols = atoi(nc);
+  if (r->ts_ncols_env) ts.ncols = r->ts_ncols_env;   // (the switches are read once, when the handle is made: a getenv per
+                                                      //  call is a walk through the whole environment)
   ts.n_sol = compute_solar ? r->sol_n : 0; ts.sol_lo = r->sol_lo;
   ts.n_ir = r->ir_n; ts.ir_lo = r->ir_lo;
   ts.sol_start = r->sol.ind_start; ts.ir_start = r->ir.ind_start;
@@ -641,8 +644,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     pp.call_id = ++r->call_id;
     {  // when the wave-per-column two-stream kernel will add two g-point groups into its
        // outputs, let spare blocks of this launch clear them (saves a launch)
-      const char *mode = getenv("CLIMA_HIP_TS_MODE");
-      const bool wave_mode = !(mode && std::strcmp(mode, "block") == 0) && (nz + 63) / 64 <= 8;
+      const bool wave_mode = !r->ts_block_mode && (nz + 63) / 64 <= 8;
       pre_zeroed = false;
       // (not when the fused grid will run its half-wave form: those blocks store whole values -- 7.7 MB of
       // zeros per config-2 call that nobody reads)
@@ -743,9 +745,8 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
   if (!fused_done) {
     KernelTimer t(r, 2);
     // default: wave-per-column kernel; CLIMA_HIP_TS_MODE=block selects the workgroup-per-bin form
-    const char *mode = getenv("CLIMA_HIP_TS_MODE");
     bool ok = false;
-    if (!(mode && std::strcmp(mode, "block") == 0) && ts.nzen <= MAX_ZEN) ok = launch_twostream_w(ts, r->stream, &r->ts_lds, pre_zeroed);
+    if (!r->ts_block_mode && ts.nzen <= MAX_ZEN) ok = launch_twostream_w(ts, r->stream, &r->ts_lds, pre_zeroed);
     if (!ok) { HIPCHK(hipGetLastError()); ok = launch_twostream(ts, r->stream, &r->ts_lds); }
     HIPCHK(hipGetLastError());
     if (!ok)
@@ -1288,6 +1289,8 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   HIPCHK(hipEventCreateWithFlags(&r->ev_upload, hipEventDisableTiming));
   if (const char *f = getenv("CLIMA_HIP_FUSED")) r->fused = atoi(f) != 0;
   if (const char *f = getenv("CLIMA_HIP_GENERIC")) r->generic_opacity = atoi(f) != 0;
+  if (const char *f = getenv("CLIMA_HIP_TS_MODE")) r->ts_block_mode = std::strcmp(f, "block") == 0;
+  if (const char *f = getenv("CLIMA_HIP_TS_NCOLS")) r->ts_ncols_env = atoi(f);
   if (const char *f = getenv("CLIMA_HIP_BATCH_SHARED")) r->batch_shared = atoi(f) != 0;
   if (const char *f = getenv("CLIMA_HIP_FUSED_SPINS")) r->fused_max_spins = std::max(0, atoi(f));  // test aid: 0 makes waits expire
 
@@ -1545,8 +1548,7 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
   // turn, so one column's two-stream tail runs beside the next column's opacity tiles) where the fused
   // form covers the configuration; otherwise the calls of the columns are enqueued back to back.
   const int CH = std::min(n, r->batch_cols_in_flight);
-  const char *ts_mode = getenv("CLIMA_HIP_TS_MODE");
-  bool one_launch = r->fused && r->ng == 8 && !(ts_mode && std::strcmp(ts_mode, "block") == 0) && (nz + 63) / 64 >= 2 && (nz + 63) / 64 <= 8 &&
+  bool one_launch = r->fused && r->ng == 8 && !r->ts_block_mode && (nz + 63) / 64 >= 2 && (nz + 63) / 64 <= 8 &&
                     (int)r->zenith_u.size() <= MAX_ZEN && !((nz + 63) / 64 > 4 && (r->rebin_mode != 0 || r->cust_on)) &&
                     integrate_chunks(std::max(r->ir_n, r->sol_n)) * (32 + 16) * sizeof(double) <= 64 * 1024;
   if (const char *e = getenv("CLIMA_HIP_BATCH_ONE_LAUNCH")) one_launch = one_launch && atoi(e) != 0;
