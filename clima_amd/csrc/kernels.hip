@@ -3549,11 +3549,14 @@ __global__ __launch_bounds__(INT_LV * INT_CG) void k_integrate_one(IntegratePara
     const int t = *p.timeout_flag;   // the fused grid of this call has drained: the word is final
     *p.timeout_out = (t == p.id_opr ? 1.0 : 0.0) + (t == p.id_sol ? 1024.0 : 0.0);
   }
+  if (p.host_out && a == 0 && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x < 2)   // the error words ride along
+    reinterpret_cast<int *>(p.host_out + 5 * nl)[threadIdx.x] = p.err_words[threadIdx.x];
   if (sol && !p.do_solar) {
     // solar rows keep the last solar call's values (clima_radtran.f90:286-289).  On a bin-sharded
     // handle flux_n is the all-reduce buffer and holds REDUCED rows by now: this rank's partial
     // solar rows are put back from flux_part, or the next reduce would count them `world` times
     if (p.flux_part && cg == 0 && i < nl) p.flux_n[a * nl + i] = p.flux_part[a * nl + i];
+    if (p.host_out && cg == 0 && i < nl) p.host_out[a * nl + i] = p.flux_n[a * nl + i];
     return;
   }
   const int cb = blockIdx.z;  // column of a batch
@@ -3593,7 +3596,13 @@ __global__ __launch_bounds__(INT_LV * INT_CG) void k_integrate_one(IntegratePara
     for (int k = 0; k < p.nchunk; k++) acc = acc + s_part[k * INT_LV + lv];
     flux_n[a * nl + i] = acc;
     if (p.flux_part) p.flux_part[a * nl + i] = acc;
+    if (p.host_out) p.host_out[a * nl + i] = acc;
   }
+}
+
+// true when launch_integrate() takes the one-launch kernel (the form that can store into the host's block)
+bool integrate_one_launch(const IntegrateParams &p) {
+  return sizeof(double) * (size_t)p.nchunk * (INT_CHUNK + INT_LV) <= 64 * 1024;
 }
 
 void launch_integrate(const IntegrateParams &p, hipStream_t s) {

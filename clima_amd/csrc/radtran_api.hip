@@ -190,6 +190,9 @@ struct Radtran {
   DevBuf<double> d_small;     // flux_n[4*(nz+1)] | f_total[nz+1] | err flag slot: one D2H copy per call
   DevBuf<double> d_flux_n, d_f_total;   // views into d_small
   double *h_small = nullptr;  // pinned: flux_n[4*(nz+1)] | f_total[nz+1] | err flag (as double slot)
+  double *h_small_dev = nullptr;   // the same block as the device addresses it (null: not mapped)
+  bool want_host_out = false;      // set by the synchronous wrappers around their enqueue_radiate
+  bool small_in_host = false;      // the last call's integration stored its rows into h_small itself: no copy to fetch them
   int *h_errflag = nullptr;
   std::vector<double> f_total;
   bool small_valid = false;
@@ -769,6 +772,14 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
   ip.nchunk = integrate_chunks(std::max(r->ir_n, r->sol_n));
   ip.partial = r->d_partial.p;
   const bool reduce = r->comm && !bc && !r->col_override;
+  // a synchronous call on an unsharded handle: the integration kernel stores the level rows and the error words into
+  // the host's pinned block as well, and the call ends with a stream synchronise -- no copy launch in front of it
+  r->small_in_host = false;
+  if (r->want_host_out && r->h_small_dev && !bc && !r->col_override && !reduce && r->shard_world == 1 && integrate_one_launch(ip)) {
+    ip.host_out = r->h_small_dev;
+    ip.err_words = r->d_err.p;
+    r->small_in_host = true;
+  }
   if (reduce) {
     // the status word rides on the all-reduce in the slot behind the four level rows (f_total's first element:
     // on such a handle f_total is formed on the host from the REDUCED rows, fetch_small)
@@ -792,7 +803,8 @@ void fetch_small(Radtran *r) {
   if (r->small_valid) return;
   const int nl = r->nz + 1;
   for (int pass = 0; pass < 2; pass++) {
-    HIPCHK(hipMemcpyAsync(r->h_small, r->d_small.p, sizeof(double) * (5 * nl + 1), hipMemcpyDeviceToHost, r->stream));
+    if (!r->small_in_host)
+      HIPCHK(hipMemcpyAsync(r->h_small, r->d_small.p, sizeof(double) * (5 * nl + 1), hipMemcpyDeviceToHost, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream));
     resolve_events(r);
     if (r->comm) r->comm_status = r->h_small[4 * nl];
@@ -1396,8 +1408,12 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   r->d_err.view(reinterpret_cast<int *>(r->d_small.p + (size_t)5 * (nz + 1)), 2);
   r->d_partial.alloc((size_t)4 * integrate_chunks(std::max(r->ir.nw, r->sol.nw)) * (nz + 1)); r->d_partial.zero();
   r->d_f_total.view(r->d_small.p + (size_t)4 * (nz + 1), nz + 1);
-  HIPCHK(hipHostMalloc((void **)&r->h_small, sizeof(double) * (5 * (nz + 1) + 1)));
+  HIPCHK(hipHostMalloc((void **)&r->h_small, sizeof(double) * (5 * (nz + 1) + 1), hipHostMallocMapped));
   std::memset(r->h_small, 0, sizeof(double) * (5 * (nz + 1) + 1));
+  {
+    static const bool direct = [] { const char *e = getenv("CLIMA_HIP_HOST_OUT"); return !(e && e[0] == '0'); }();
+    if (!direct || hipHostGetDevicePointer((void **)&r->h_small_dev, r->h_small, 0) != hipSuccess) { r->h_small_dev = nullptr; (void)hipGetLastError(); }
+  }
   r->h_errflag = reinterpret_cast<int *>(r->h_small + 5 * (nz + 1));
   r->f_total.assign(nz + 1, 0.0);
   HIPCHK(hipDeviceSynchronize());
@@ -1602,7 +1618,7 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
     fell_back = true;
   }
   r->checked_timeout = r->call_id;
-  r->small_valid = false;
+  r->small_valid = false; r->small_in_host = false;   // (the device rows changed: fetch them)
   r->column_loaded = false;   // d_col does not hold the last column: a resident call needs an upload first
   // What the handle holds afterwards is the LAST column's, like after n single calls: its level rows (copied above),
   // and its spectra / band optical depths -- the one-launch form left those in the batch arena (copied here);
@@ -1677,7 +1693,14 @@ void radtran_radiate_wrapper(void *ptr, const double *T_surface, const int *dim_
 #ifdef CLIMA_TRACE_SYNC
   const double t1 = now();
 #endif
-  enqueue_radiate(r, *compute_solar != 0, *compute_opacity != 0);
+  r->want_host_out = true;
+  try {
+    enqueue_radiate(r, *compute_solar != 0, *compute_opacity != 0);
+  } catch (...) {
+    r->want_host_out = false;
+    throw;
+  }
+  r->want_host_out = false;
 #ifdef CLIMA_TRACE_SYNC
   const double t2 = now();
 #endif
@@ -1760,7 +1783,7 @@ void radtran_apply_radiation_enhancement(void *ptr, const double *rad_enhancemen
     // (with a communicator the slot behind the rows carries the step's status word, and f_total is formed on the host
     // from the rows in any case: fetch_small)
     if (!r->comm) launch_f_total(r->nz, r->d_flux_n.p, r->d_f_total.p, r->stream);
-    r->small_valid = false;
+    r->small_valid = false; r->small_in_host = false;   // (the device rows changed: fetch them)
     fetch_small(r);
     for (int i = 0; i < nl; i++) r->f_total[i] = r->h_small[4 * nl + i];
   } catch (...) {
@@ -1919,7 +1942,7 @@ void radtran_finish_reduced(void *ptr, char *err) {
   // f_total = (sol_dn - sol_up) + (ir_dn - ir_up) of the reduced rows is formed on the host when the
   // results are fetched (fetch_small), like after every call: nothing to launch here, the level
   // rows just have to be read again
-  r->small_valid = false;
+  r->small_valid = false; r->small_in_host = false;   // (the device rows changed: fetch them)
 }
 
 void radtran_stream_get(void *ptr, void **stream) {

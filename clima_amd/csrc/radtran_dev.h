@@ -243,6 +243,11 @@ struct IntegrateParams {
   double *timeout_out;
   const int *timeout_flag;
   int id_opr, id_sol;
+  // synchronous entry points (radtran_radiate_wrapper): the four level rows and the two device error words are
+  // ALSO stored straight into the host's pinned result block (device address of it), so that the call ends with a
+  // stream synchronise instead of a copy launch + synchronise.  Null otherwise.
+  double *host_out;
+  const int *err_words;
 };
 
 struct BatchIntegrateParams {
@@ -273,6 +278,7 @@ bool launch_fused_twostream_only(TwoStreamParams &ts, int slots, const int *meta
 int twostream_w_groups(int ng);
 int twostream_w_half_slots(const TwoStreamParams &p);   // > 0: launch_twostream_w takes k_twostream_h (with 8 g-points: stores whole values)
 void launch_integrate(const IntegrateParams &p, hipStream_t s);
+bool integrate_one_launch(const IntegrateParams &p);
 void launch_integrate_batch(const BatchIntegrateParams &p, int ncol, hipStream_t s);
 int integrate_chunks(int nbins);
 void launch_f_total(int nz, const double *flux_n, double *f_total, hipStream_t s);
