@@ -1245,20 +1245,21 @@ __device__ __forceinline__ double group_sum(double v) {
   else return v;
 }
 
-// blocks of 4 waves per CU the kernel is compiled for: its lane exchanges make it latency-bound, so waves per SIMD count
+// waves per SIMD the kernel is compiled for (__launch_bounds__' second argument): its lane exchanges make it
+// latency-bound, so they count
 // (measured, profiles/r03_coop_ab.txt: 16 g-points at three waves per SIMD instead of two -- 168 registers, 14-22
 // scratch accesses outside the sort -- 610 -> 541 us; 8 g-points forced from three to four: slower, left alone;
 // 32 g-points at two instead of one: 4.67 -> 2.92 ms)
-#ifndef COOP_BLOCKS_8
-#define COOP_BLOCKS_8 1
+#ifndef COOP_WAVES_8
+#define COOP_WAVES_8 1
 #endif
-#ifndef COOP_BLOCKS_16
-#define COOP_BLOCKS_16 3
+#ifndef COOP_WAVES_16
+#define COOP_WAVES_16 3
 #endif
-#ifndef COOP_BLOCKS_32
-#define COOP_BLOCKS_32 2
+#ifndef COOP_WAVES_32
+#define COOP_WAVES_32 2
 #endif
-#define COOP_MIN_BLOCKS(NG) ((NG) == 8 ? COOP_BLOCKS_8 : (NG) == 16 ? COOP_BLOCKS_16 : COOP_BLOCKS_32)
+#define COOP_MIN_WAVES(NG) ((NG) == 8 ? COOP_WAVES_8 : (NG) == 16 ? COOP_WAVES_16 : COOP_WAVES_32)
 template <int NG>
 struct CoopSort {
   // one step with partner position pos ^ X restricted to partners in another lane: lane ^ LM, register
@@ -1315,7 +1316,7 @@ struct CoopSort {
 };
 
 template <int NG, bool CUSTOM>
-__global__ __launch_bounds__(OP_THREADS, COOP_MIN_BLOCKS(NG)) void k_opacity_coop(OpacityParams p) {
+__global__ __launch_bounds__(OP_THREADS, COOP_MIN_WAVES(NG)) void k_opacity_coop(OpacityParams p) {
   constexpr int N2 = NG * NG, GROUPS = OP_THREADS / NG;
   constexpr unsigned long long IDX_MASK = (unsigned long long)(N2 - 1);
   __shared__ double s_wxy[N2];
@@ -3014,6 +3015,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_twostream_ir_batch(TwoStreamPara
   // data.  Their per-step multipliers live in LDS, one slot per thread and step: they are read
   // once per column and would otherwise cost 28 VGPRs.
   // (the four-wave form has the SIMD's whole register file: there they stay in registers)
+  // (measured for the 1- and 2-slot instances of the 8-wave form as well, to fit two blocks per CU: 4.6 -> 4.8 us per
+  // column at 102 layers with the table gone, 10.3 when also compiled for four waves per SIMD -- spills)
   constexpr bool STEP_REGS = NW == 4;
   double *sStep = sF0 + (size_t)4 * NW * (nl + 1) + threadIdx.x;  // [2 * WSCAN_STEPS][blockDim.x]
   double stA[WSCAN_STEPS], stB[WSCAN_STEPS];
