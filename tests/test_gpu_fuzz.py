@@ -73,7 +73,17 @@ def _yardstick(O, tb, nz, nzen, albedo, col, scalars, surf):
     return max(float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(a))), 1e-300)) for a, b in zip(*outs))
 
 
-@pytest.mark.parametrize("seed", range(160))
+def _seeds():
+    """160 seeds in the suite; CLIMA_FUZZ_SEEDS=a:b runs another range (a longer one-off sweep)."""
+    import os
+    e = os.environ.get("CLIMA_FUZZ_SEEDS")
+    if e:
+        a, b = (int(x) for x in e.split(":"))
+        return range(a, b)
+    return range(160)
+
+
+@pytest.mark.parametrize("seed", _seeds())
 def test_random_inventory_and_column(O, seed):
     from test_gpu_parity import TOL_LEVEL
     tb, nz, nzen, albedo, col, scalars, rng = _case(seed)
