@@ -3358,9 +3358,9 @@ static int half_slots(const OpacityParams &op, const TwoStreamParams &ts) {
 // slots of the half-wave form when launch_fused() will take it for this call, else 0.  Its blocks hold all 8
 // g-points of a bin and store every output value themselves: the caller need not clear the outputs first.
 int fused_half_form(const OpacityParams &op, const TwoStreamParams &ts, int ncol) {
+  (void)ncol;
   if (!fused_supported(op, ts)) return 0;
-  if (ncol <= 1 && paired_slots(op, ts)) return 0;
-  return half_slots(op, ts);
+  return half_slots(op, ts);   // (taken before the paired form wherever both apply: launch_fused)
 }
 static FusedKern fused_kernel_half(int slots) {
   static const FusedKern k[5] = {k_fused<0, false, 3, false, true>, k_fused<0, false, 4, false, true>, k_fused<0, false, 5, false, true>,
@@ -3383,9 +3383,12 @@ bool launch_fused(const OpacityParams &op, TwoStreamParams &ts, FusedParams fp, 
   fp.n_op = fused_tiles(op);
   fp.n_ts = nb * groups;
   fp.slots = (ts.nz + 63) / 64;  // 2..8 (fused_supported)
-  const int ps = fp.ncol <= 1 ? paired_slots(op, ts) : 0;   // (a batch's columns are not all pairs)
+  // 65-224 layers: the half-wave form, also on an all-pairs grid (round 3, measured on AdiabatClimate's doubled grids:
+  // 102 layers 66.3 against 69.1 us per call in the paired whole-wave form, 202 layers 78.2 against 80.6); the paired
+  // form takes the all-pairs grids beyond (402 layers: 131 against ~145 unpaired)
+  const int hs = half_slots(op, ts);
+  const int ps = (!hs && fp.ncol <= 1) ? paired_slots(op, ts) : 0;   // (a batch's columns are not all pairs)
   if (ps) fp.slots = ps;
-  const int hs = ps ? 0 : half_slots(op, ts);
   if (hs) { fp.slots = hs; fp.n_ts = nb; }
   if (fp.ncol < 1) fp.ncol = 1;
   {

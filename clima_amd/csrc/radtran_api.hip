@@ -218,7 +218,7 @@ struct Radtran {
   int batch_cols_in_flight = 64;
   bool batch_shared = true;        // radiate_ir_batch: temperature-independent work shared by the columns (CLIMA_HIP_BATCH_SHARED=0: one full solve per column)
   int rebin_mode = 1;              // 0 window form, 1 streaming, 2 streaming multi-edge (rebin_mode_for)
-  long coop_items = 28672;         // ng = 8: at most this many (bin, source layer) items go to k_opacity_coop<8> (CLIMA_HIP_COOP_ITEMS)
+  long coop_items = 34816;         // ng = 8: at most this many (bin, source layer) items go to k_opacity_coop<8> (CLIMA_HIP_COOP_ITEMS)
   bool fused = true;               // opacity + two-stream in one grid (k_fused); CLIMA_HIP_FUSED=0 or radtran_fused_set turns it off
   bool generic_opacity = false;    // g-point counts other than 8: k_opacity_generic instead of the group-of-lanes kernel (CLIMA_HIP_GENERIC=1)
   bool ts_block_mode = false;      // CLIMA_HIP_TS_MODE=block when the handle was made: the workgroup-per-bin two-stream kernel

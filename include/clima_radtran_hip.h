@@ -201,7 +201,7 @@ void radtran_fused_get(void *ptr, int *enabled);
 /* With 8 g-points, calls with at most `items` (bin, source layer) items -- a bin-sharded rank, a short
  * column -- run the opacity work in the group-of-lanes kernel (8 lanes per item: a fifth of the
  * dependent chain of the lane-per-item kernel at 2.4x its total work) with one launch per kernel;
- * larger calls take the lane-per-item kernel inside the fused grid.  Default 28672
+ * larger calls take the lane-per-item kernel inside the fused grid.  Default 34816
  * (CLIMA_HIP_COOP_ITEMS); 0 turns the group-of-lanes form off.  Same results to rounding (6e-14). */
 void radtran_coop_items_set(void *ptr, const int *items);
 void radtran_coop_items_get(void *ptr, int *items);

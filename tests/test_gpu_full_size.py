@@ -299,8 +299,9 @@ def test_config4_1024_perturbed_columns_at_full_size(O, nominal):
 def test_doubled_radiative_grid_takes_the_paired_two_stream_form(O, nz_adiabat, nw):
     """AdiabatClimate's radiative grid (copy_atm_to_radiative_grid, src/adiabat/clima_adiabat.f90:729-773:
     nz_r = 2 nz + 2, every pair of layers identical) with enough bins for the fused grid: the opacity lanes
-    exist per source layer only, and the two-stream part runs in its paired form (2, 4, 6, 8 slots:
-    coefficients computed once per pair).  Against the oracle at the usual tolerances."""
+    exist per source layer only, and the two-stream part runs in its half-wave form up to 224 layers (102, 202: faster
+    there than the paired form, round 3) and in its paired form beyond (302, 402 layers: 6, 8 slots, coefficients
+    computed once per pair).  Against the oracle at the usual tolerances."""
     from clima_amd import synthetic as S
     from clima_amd.atmosphere import copy_atm_to_radiative_grid
     from clima_amd.radtran import Radtran
