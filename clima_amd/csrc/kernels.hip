@@ -3513,10 +3513,10 @@ __global__ __launch_bounds__(256) void k_integrate_final_b(BatchIntegrateParams 
       up = up + p.partial[(((size_t)col * 2 + 0) * p.nchunk + k) * nl + i];
       dn = dn + p.partial[(((size_t)col * 2 + 1) * p.nchunk + k) * nl + i];
     }
-    double *o = p.out + (size_t)(p.col0 + col) * 3 * nl;
+    double *o = p.out + (size_t)(p.col0 + col) * nl;
     o[i] = up;
-    o[nl + i] = dn;
-    o[2 * nl + i] = (p.flux_n[3 * nl + i] - p.flux_n[2 * nl + i]) + (dn - up);  // clima_radtran.f90:287
+    o[p.out_arr + i] = dn;
+    o[2 * p.out_arr + i] = (p.flux_n[3 * nl + i] - p.flux_n[2 * nl + i]) + (dn - up);  // clima_radtran.f90:287
   }
 }
 
@@ -3694,5 +3694,7 @@ void launch_scale(double *a, size_t n, double f, hipStream_t s) {
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(k_scale, dim3(grid), dim3(256), 0, s, a, n, f);
 }
+
+#include "ir_green.inc"
 
 }  // namespace clima

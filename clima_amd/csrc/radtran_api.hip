@@ -154,6 +154,15 @@ struct Radtran {
   DevBuf<double> d_cust_axis, d_cust_dtau, d_cust_w0, d_cust_g0;
   // batched shared-opacity IR calls (radtran_radiate_ir_batch)
   DevBuf<double> d_bT, d_bTs, d_bup, d_bdn, d_bpartial, d_bout;
+  // ... and its response form (ir_green.inc): work arrays, deviation lists, the general sub-batch's rows
+  DevBuf<double> d_green, d_green_in, d_gen_out;
+  double *h_bout = nullptr;        // pinned: the batch's three result arrays on their way to the caller's
+  size_t h_bout_n = 0;
+  char *h_green = nullptr;         // pinned: what the host hands the response form (base profile, deviation lists)
+  size_t h_green_n = 0;
+  DevBuf<int> d_green_idx;
+  int ir_green_mode = 1;           // CLIMA_HIP_IR_GREEN: 0 never, 1 when enough columns are sparse deviations of one profile, 2 whenever any is
+  long ir_green_batches = 0;       // batches that took the response form (radtran_ir_green_batches_get)
   DevBuf<double> d_col;  // [T_surface | T | P | dz | dens | pdens | radii | meta (ints: nsrc, source list, source of every layer)]
   size_t meta_ofs = 0;   // doubles before the meta ints in a column block
   int nsrc = 0;          // source layers of the resident column (pair_reuse decided at upload)
@@ -244,6 +253,8 @@ struct Radtran {
     for (auto &e : pool) (void)hipEventDestroy(e);
     if (h_col) (void)hipHostFree(h_col);
     if (h_small) (void)hipHostFree(h_small);
+    if (h_bout) (void)hipHostFree(h_bout);
+    if (h_green) (void)hipHostFree(h_green);
     if (ev_upload) (void)hipEventDestroy(ev_upload);
     if (comm) (void)ncclCommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1258,6 +1269,15 @@ void radtran_coop_items_get(void *ptr, int *items) {
   Radtran *r = as_rad(ptr);
   *items = r ? (int)std::min<long>(r->coop_items, 2147483647L) : 0;
 }
+void radtran_ir_green_set(void *ptr, const int *mode) {
+  Radtran *r = as_rad(ptr);
+  if (r) r->ir_green_mode = std::max(0, std::min(2, *mode));
+}
+void radtran_ir_green_get(void *ptr, int *mode, int *batches) {
+  Radtran *r = as_rad(ptr);
+  *mode = r ? r->ir_green_mode : 0;
+  *batches = r ? (int)std::min<long>(r->ir_green_batches, 2147483647L) : 0;
+}
 void radtran_fused_fallbacks_get(void *ptr, int *count) {
   Radtran *r = as_rad(ptr);
   *count = r ? r->fused_fallbacks : 0;
@@ -1304,6 +1324,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   if (const char *f = getenv("CLIMA_HIP_TS_MODE")) r->ts_block_mode = std::strcmp(f, "block") == 0;
   if (const char *f = getenv("CLIMA_HIP_TS_NCOLS")) r->ts_ncols_env = atoi(f);
   if (const char *f = getenv("CLIMA_HIP_BATCH_SHARED")) r->batch_shared = atoi(f) != 0;
+  if (const char *f = getenv("CLIMA_HIP_IR_GREEN")) r->ir_green_mode = std::max(0, std::min(2, atoi(f)));
   if (const char *f = getenv("CLIMA_HIP_FUSED_SPINS")) r->fused_max_spins = std::max(0, atoi(f));  // test aid: 0 makes waits expire
 
   // ---- tables to HBM + interpolation slots
@@ -1450,19 +1471,10 @@ void radtran_radiate_resident(void *ptr, const int *compute_solar, const int *co
 // one `radiate(..., compute_solar=.false., compute_opacity=.false.)` per perturbed temperature
 // profile).  Column c gets what that call would leave in wrk_ir%fup_n, wrk_ir%fdn_n and f_total
 // (clima_radtran.f90:262-289: IR with the resident opr, solar terms of the last solar call).
-void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
-                              const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
-                              double *f_total, char *err) {
-  clear_err(err);
-  GUARD(r, ptr, err);
-  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
-  if (*dim1_T != r->nz || *dim2_T != *ncol || *ncol < 1) { set_err(err, "\"T\" has the wrong input dimension."); return; }
-  if (!r->opr_valid) { set_err(err, "radiate_ir_batch needs opacities: call radiate with compute_opacity first"); return; }
-  if (r->shard_world != 1) { set_err(err, "radiate_ir_batch is not available on a bin-sharded handle"); return; }
-  TRY
-  upload_fields(r);
-  ensure_w0(r);
-  const int nz = r->nz, nl = nz + 1, n = *ncol, nw_ir = r->ir.nw;
+//
+// The general form: n columns at d_T [n][nz], d_Ts [n] (device) -> three arrays [n][nz+1] at d_out, out_arr elements apart.
+static void ir_batch_general(Radtran *r, const double *d_T, const double *d_Ts, int n, double *d_out, size_t out_arr) {
+  const int nz = r->nz, nl = nz + 1, nw_ir = r->ir.nw;
   // columns per launch: bounds the per-column spectra held in HBM (2.5 GB at 512 layers: 288 GB make that a
   // non-issue) and sets how many columns share one evaluation of the temperature-independent part -- a block of
   // the shared-matrix kernel takes a quarter of them: at 64 per launch that part was a fifth of the kernel
@@ -1470,10 +1482,7 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   const int nchunk = integrate_chunks(r->ir_n);
   const size_t spec = (size_t)nw_ir * nl;
   auto ensure = [](DevBuf<double> &b, size_t count) { if (b.n < count) b.alloc(count); };  // grow-only
-  ensure(r->d_bT, (size_t)n * nz); ensure(r->d_bTs, n); ensure(r->d_bout, (size_t)n * 3 * nl);
   ensure(r->d_bup, spec * CH); ensure(r->d_bdn, spec * CH); ensure(r->d_bpartial, (size_t)CH * 2 * nchunk * nl);
-  HIPCHK(hipMemcpyAsync(r->d_bT.p, T, sizeof(double) * (size_t)n * nz, hipMemcpyHostToDevice, r->stream));
-  HIPCHK(hipMemcpyAsync(r->d_bTs.p, T_surface, sizeof(double) * n, hipMemcpyHostToDevice, r->stream));
   ColumnDev col = column_dev(r);
   TwoStreamParams ts = make_twostream_params(r, col, false);
   ts.ir_fup_a = r->d_bup.p; ts.ir_fdn_a = r->d_bdn.p;
@@ -1482,7 +1491,7 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   for (int c0 = 0; c0 < n; c0 += CH) {
     const int nc = std::min(CH, n - c0);
     TwoStreamParams tb = ts;
-    tb.T = r->d_bT.p + (size_t)c0 * nz; tb.T_surface = r->d_bTs.p + c0; tb.b_ncol = nc;
+    tb.T = d_T + (size_t)c0 * nz; tb.T_surface = d_Ts + c0; tb.b_ncol = nc;
     // shared-matrix batch kernel (up to 512 layers); otherwise one full solve per column
     const bool shared_ok = r->batch_shared && launch_twostream_ir_batch(tb, nc, r->stream);
     HIPCHK(hipGetLastError());
@@ -1500,19 +1509,193 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     std::memset(&bp, 0, sizeof(bp));
     bp.nz = nz; bp.ir_lo = r->ir_lo; bp.ir_n = r->ir_n; bp.nchunk = nchunk; bp.col0 = c0;
     bp.fup_a = r->d_bup.p; bp.fdn_a = r->d_bdn.p; bp.spec_stride = spec;
-    bp.freq = r->ir.d_freq.p; bp.partial = r->d_bpartial.p; bp.flux_n = r->d_flux_n.p; bp.out = r->d_bout.p;
+    bp.freq = r->ir.d_freq.p; bp.partial = r->d_bpartial.p; bp.flux_n = r->d_flux_n.p; bp.out = d_out; bp.out_arr = out_arr;
     launch_integrate_batch(bp, nc, r->stream);
     HIPCHK(hipGetLastError());
   }
-  std::vector<double> out((size_t)n * 3 * nl);
-  HIPCHK(hipMemcpyAsync(out.data(), r->d_bout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
-  for (int c = 0; c < n; c++)
-    for (int i = 0; i < nl; i++) {
-      fup_n[(size_t)c * nl + i] = out[((size_t)c * 3 + 0) * nl + i];
-      fdn_n[(size_t)c * nl + i] = out[((size_t)c * 3 + 1) * nl + i];
-      f_total[(size_t)c * nl + i] = out[((size_t)c * 3 + 2) * nl + i];
+}
+
+// The response form (ir_green.inc).  The Jacobian's columns are one base profile with one (on the doubled radiative
+// grid: a few) temperatures changed each; with the opacities fixed the IR solve is linear in the Planck values, so
+// such a column is F(base) + unit responses x Planck differences.  The plan below finds the base (per level the
+// temperature most columns carry: Boyer-Moore vote) and every column's deviations from it; a column with more than
+// GREEN_MAX_DEV of them (the surface-temperature column of a convective profile moves every layer) goes through the
+// general kernel together with the base profile itself.
+constexpr int GREEN_MAX_DEV = 8;
+struct GreenPlan {
+  std::vector<double> base;              // [nz] ground-first, then the surface temperature
+  std::vector<int> dense;                // columns for the general kernel
+  std::vector<int> col_src, col_ptr, col_dev, dev_k;
+  std::vector<double> dev_T;
+  int n_sparse = 0;
+};
+static void green_plan(const double *T, const double *Ts, int n, int nz, GreenPlan &pl) {
+  pl.base.assign(nz + 1, 0.0);
+  {
+    std::vector<int> votes(nz + 1, 0);     // one vote per level, the columns in memory order
+    for (int c = 0; c < n; c++) {
+      const double *Tc = T + (size_t)c * nz;
+      for (int j = 0; j <= nz; j++) {
+        const double v = j < nz ? Tc[j] : Ts[c];
+        if (votes[j] == 0) { pl.base[j] = v; votes[j] = 1; } else if (v == pl.base[j]) votes[j]++; else votes[j]--;
+      }
     }
+  }
+  pl.col_src.assign(n, -1);
+  std::vector<int> dk, dc; std::vector<double> dT;
+  for (int c = 0; c < n; c++) {
+    const double *Tc = T + (size_t)c * nz;
+    int found[GREEN_MAX_DEV + 1], cnt = 0;
+    for (int j = 0; j <= nz && cnt <= GREEN_MAX_DEV; j++)
+      if ((j < nz ? Tc[j] : Ts[c]) != pl.base[j]) found[cnt++] = j;
+    if (cnt > GREEN_MAX_DEV) { pl.col_src[c] = 1 + (int)pl.dense.size(); pl.dense.push_back(c); continue; }
+    pl.n_sparse++;
+    for (int i = 0; i < cnt; i++) {
+      const int j = found[i];
+      dk.push_back(j < nz ? nz - 1 - j : nz); dc.push_back(c); dT.push_back(j < nz ? Tc[j] : Ts[c]);   // (radiate.f90:65-69: level k is layer nz-1-k)
+    }
+  }
+  std::vector<int> order(dk.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dk[a] < dk[b]; });
+  pl.dev_k.resize(order.size()); pl.dev_T.resize(order.size());
+  std::vector<int> cnt(n + 1, 0);
+  for (size_t s2 = 0; s2 < order.size(); s2++) { pl.dev_k[s2] = dk[order[s2]]; pl.dev_T[s2] = dT[order[s2]]; cnt[dc[order[s2]] + 1]++; }
+  pl.col_ptr.assign(n + 1, 0);
+  for (int c = 0; c < n; c++) pl.col_ptr[c + 1] = pl.col_ptr[c] + cnt[c + 1];
+  pl.col_dev.resize(order.size());
+  std::vector<int> fill(pl.col_ptr.begin(), pl.col_ptr.end() - 1);
+  for (size_t s2 = 0; s2 < order.size(); s2++) pl.col_dev[fill[dc[order[s2]]]++] = (int)s2;
+}
+
+static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, const double *Ts, int n, double *d_out) {
+  const int nz = r->nz, nl = nz + 1, N = 2 * nz, ng = r->ng, n_ir = r->ir_n;
+  const int NQ = n_ir * ng;
+  auto ensure = [](DevBuf<double> &b, size_t count) { if (b.n < count) b.alloc(count); };
+  // 1. the base profile and the dense columns through the general kernel
+  const int ngen = 1 + (int)pl.dense.size();
+  const int ndev = (int)pl.dev_k.size(), ndev_pad = std::max(16, (ndev + 15) / 16 * 16);
+  std::vector<int> mdev, mblk;           // the level blocks around a deviation's own levels (green_block_class == 2)
+  for (int d = 0; d < ndev; d++)
+    for (int blk = std::max(0, (pl.dev_k[d] - 1) / 16 - 1); blk < (nl + 15) / 16; blk++) {
+      const int cls = green_block_class(pl.dev_k[d], blk, nz);
+      if (cls == 2) { mdev.push_back(d); mblk.push_back(blk); }
+      if (cls == 1) break;
+    }
+  const int nmix = (int)mdev.size();
+  // everything the host hands over goes through ONE pinned block (no pageable copies, no synchronise before the
+  // kernels): doubles T [ngen][nz] | Ts [ngen] | dev_T [ndev_pad] | base_T by level k [nl], then ints
+  // dev_k [ndev_pad] | col_src [n] | col_ptr [n+1] | col_dev [ndev] | mix_dev [nmix] | mix_blk [nmix]
+  const size_t nd = (size_t)ngen * nz + ngen + ndev_pad + nl, ni = (size_t)ndev_pad + n + (n + 1) + ndev + 2 * (size_t)nmix;
+  const size_t stage_bytes = sizeof(double) * nd + sizeof(int) * ni;
+  if (r->h_green_n < stage_bytes) {
+    if (r->h_green) (void)hipHostFree(r->h_green);
+    r->h_green = nullptr; r->h_green_n = 0;
+    HIPCHK(hipHostMalloc((void **)&r->h_green, stage_bytes + stage_bytes / 2, hipHostMallocDefault));
+    r->h_green_n = stage_bytes + stage_bytes / 2;
+  }
+  double *hd = reinterpret_cast<double *>(r->h_green);
+  int *hi = reinterpret_cast<int *>(hd + nd);
+  {
+    double *hT = hd, *hTs = hd + (size_t)ngen * nz, *hdev = hTs + ngen, *hbase = hdev + ndev_pad;
+    std::memcpy(hT, pl.base.data(), sizeof(double) * nz);
+    hTs[0] = pl.base[nz];
+    for (int i = 1; i < ngen; i++) {
+      std::memcpy(hT + (size_t)i * nz, T + (size_t)pl.dense[i - 1] * nz, sizeof(double) * nz);
+      hTs[i] = Ts[pl.dense[i - 1]];
+    }
+    for (int d = 0; d < ndev_pad; d++) hdev[d] = d < ndev ? pl.dev_T[d] : 0.0;
+    for (int k = 0; k < nz; k++) hbase[k] = pl.base[nz - 1 - k];
+    hbase[nz] = pl.base[nz];
+    int *w2 = hi;
+    for (int d = 0; d < ndev_pad; d++) *w2++ = d < ndev ? pl.dev_k[d] : 0;
+    w2 = std::copy(pl.col_src.begin(), pl.col_src.end(), w2);
+    w2 = std::copy(pl.col_ptr.begin(), pl.col_ptr.end(), w2);
+    w2 = std::copy(pl.col_dev.begin(), pl.col_dev.end(), w2);
+    w2 = std::copy(mdev.begin(), mdev.end(), w2);
+    w2 = std::copy(mblk.begin(), mblk.end(), w2);
+  }
+  ensure(r->d_green_in, nd); ensure(r->d_gen_out, (size_t)ngen * 3 * nl);
+  if (r->d_green_idx.n < ni) r->d_green_idx.alloc(ni);
+  HIPCHK(hipMemcpyAsync(r->d_green_in.p, hd, sizeof(double) * nd, hipMemcpyHostToDevice, r->stream));
+  HIPCHK(hipMemcpyAsync(r->d_green_idx.p, hi, sizeof(int) * ni, hipMemcpyHostToDevice, r->stream));
+  const double *d_T = r->d_green_in.p, *d_Ts = d_T + (size_t)ngen * nz;
+  ir_batch_general(r, d_T, d_Ts, ngen, r->d_gen_out.p, (size_t)ngen * nl);
+  // 3. work arrays
+  const size_t RQ = (size_t)N * NQ, LQ = (size_t)nl * NQ;
+  const int waves = ((ndev + 63) / 64) * ((nl + 15) / 16);    // of the far-form accumulation, per bin split
+  // bin splits: the accumulation's waves should fill the machine ONCE (1024 SIMDs x 3 waves of 152 registers): a few
+  // waves more than that and the kernel takes two rounds
+  const int qsplit = std::max(1, std::min(std::min(n_ir, 64), 2900 / std::max(waves, 1)));
+  const size_t FQ = (size_t)2 * ((nl + 15) / 16) * 34 * NQ;    // (GREEN_LB, GREEN_FS of ir_green.inc)
+  const size_t total = 7 * RQ + 6 * LQ + FQ + 10 * LQ + (size_t)n_ir * ndev_pad + (size_t)qsplit * ndev_pad * 2 * nl;
+  ensure(r->d_green, total);
+  GreenParams g;
+  std::memset(&g, 0, sizeof(g));
+  g.nz = nz; g.ng = ng; g.n_ir = n_ir; g.ir_lo = r->ir_lo; g.ir_start = r->ir.ind_start; g.NQ = NQ;
+  g.tau = r->d_tau.p; g.w0 = r->d_w0.p; g.g = r->d_g.p; g.wbin = r->d_wbin.p;
+  g.freq = r->d_freq.p; g.ir_freq = r->ir.d_freq.p; g.emissivity = r->d_emis.p;
+  g.has_hard_surface = r->has_hard_surface ? 1 : 0; g.ir_tau_min = r->ir_tau_min;
+  double *w = r->d_green.p;
+  auto take = [&](size_t cnt) { double *p0 = w; w += cnt; return p0; };
+  g.RW = take(7 * RQ);
+  g.IS = take(6 * LQ); g.FS = take(FQ); g.DS = take(10 * LQ);
+  g.DB = take((size_t)n_ir * ndev_pad); g.partial = take((size_t)qsplit * ndev_pad * 2 * nl);
+  g.ndev = ndev; g.ndev_pad = ndev_pad; g.qsplit = qsplit;
+  g.dev_k = r->d_green_idx.p; g.col_src = g.dev_k + ndev_pad; g.col_ptr = g.col_src + n; g.col_dev = g.col_ptr + n + 1;
+  g.nmix = nmix; g.mix_dev = g.col_dev + ndev; g.mix_blk = g.mix_dev + nmix;
+  g.dev_T = d_Ts + ngen; g.base_T = g.dev_T + ndev_pad;
+  g.gen_out = r->d_gen_out.p; g.gen_arr = (size_t)ngen * nl; g.flux_n = r->d_flux_n.p; g.out = d_out; g.out_arr = (size_t)n * nl;
+  launch_green_factor(g, r->stream);
+  HIPCHK(hipGetLastError());
+  launch_green_columns(g, n, r->stream);
+  HIPCHK(hipGetLastError());
+  r->ir_green_batches++;
+}
+
+void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
+                              const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
+                              double *f_total, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
+  if (*dim1_T != r->nz || *dim2_T != *ncol || *ncol < 1) { set_err(err, "\"T\" has the wrong input dimension."); return; }
+  if (!r->opr_valid) { set_err(err, "radiate_ir_batch needs opacities: call radiate with compute_opacity first"); return; }
+  if (r->shard_world != 1) { set_err(err, "radiate_ir_batch is not available on a bin-sharded handle"); return; }
+  TRY
+  upload_fields(r);
+  ensure_w0(r);
+  const int nz = r->nz, nl = nz + 1, n = *ncol;
+  auto ensure = [](DevBuf<double> &b, size_t count) { if (b.n < count) b.alloc(count); };  // grow-only
+  ensure(r->d_bout, (size_t)n * 3 * nl);
+  bool green = false;
+  if (r->ir_green_mode != 0 && r->batch_shared && nz >= 4 && nz <= 512 && r->ir_n > 0) {   // (CLIMA_HIP_BATCH_SHARED=0: one full solve per column, bit for bit the single call)
+    GreenPlan pl;
+    green_plan(T, T_surface, n, nz, pl);
+    // worth it from a few dozen sparse columns of a tall grid on (measured: 203 columns x 202 layers 0.78 against 1.28 ms,
+    // 103 x 102: 0.54 against 0.46 -- the general kernel's 1-2 slot forms are cheap and the opacity-only pass is not free)
+    green = r->ir_green_mode == 2 ? pl.n_sparse > 0 : (pl.n_sparse >= 48 && (long)pl.n_sparse * nz >= 20000);
+    if (green) ir_batch_green(r, pl, T, T_surface, n, r->d_bout.p);
+  }
+  if (!green) {
+    ensure(r->d_bT, (size_t)n * nz); ensure(r->d_bTs, n);
+    HIPCHK(hipMemcpyAsync(r->d_bT.p, T, sizeof(double) * (size_t)n * nz, hipMemcpyHostToDevice, r->stream));
+    HIPCHK(hipMemcpyAsync(r->d_bTs.p, T_surface, sizeof(double) * n, hipMemcpyHostToDevice, r->stream));
+    ir_batch_general(r, r->d_bT.p, r->d_bTs.p, n, r->d_bout.p, (size_t)n * nl);
+  }
+  // the three result arrays come back through the handle's pinned block
+  const size_t arr = (size_t)n * nl;
+  if (r->h_bout_n < 3 * arr) {
+    if (r->h_bout) (void)hipHostFree(r->h_bout);
+    r->h_bout = nullptr; r->h_bout_n = 0;
+    HIPCHK(hipHostMalloc((void **)&r->h_bout, sizeof(double) * 3 * arr, hipHostMallocDefault));
+    r->h_bout_n = 3 * arr;
+  }
+  HIPCHK(hipMemcpyAsync(r->h_bout, r->d_bout.p, sizeof(double) * 3 * arr, hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  std::memcpy(fup_n, r->h_bout, sizeof(double) * arr);
+  std::memcpy(fdn_n, r->h_bout + arr, sizeof(double) * arr);
+  std::memcpy(f_total, r->h_bout + 2 * arr, sizeof(double) * arr);
   CATCH(err)
 }
 

@@ -257,8 +257,63 @@ struct BatchIntegrateParams {
   const double *freq;            // IR channel freq [nw_ir+1]
   double *partial;               // [ncol][2][nchunk][nz+1]
   const double *flux_n;          // the handle's [4][nz+1] (solar rows of the last solar call)
-  double *out;                   // [ncol_total][3][nz+1]: fup_n, fdn_n, f_total
+  double *out;                   // three arrays [ncol_total][nz+1], out_arr elements apart: fup_n, fdn_n, f_total
+  size_t out_arr;
 };
+
+constexpr int GREEN_LB = 16;                 // levels per block of the far form (ir_green.inc)
+// Which form a level takes for a deviation at k.  A unit change of bplanck[k] reaches the source terms of layers k-1 and
+// k, i.e. the rows 2k-3 .. 2k+2 of E (those that exist); the levels k and k+1 (the bottoms of these two layers) and, for
+// k <= 1, level 0 are evaluated explicitly; the levels above take the above form, those below the below form.
+//   0 above, 1 below, 2 explicit (slot: 0 level k, 1 level k+1, 2 level 0)
+__host__ __device__ inline int green_class(int lv, int k, int &slot) {
+  slot = 0;
+  if (lv >= k + 2) return 1;
+  if (lv == 0 && k <= 1) { slot = 2; return 2; }
+  if (lv <= k - 1) return 0;
+  slot = lv - k;
+  return 2;
+}
+// class of (deviation k, level block): 0 every level of the block takes the above form, 1 the below form, 2 mixed
+__host__ __device__ inline int green_block_class(int k, int blk, int nz) {
+  const int lv0 = blk * GREEN_LB, lv1 = lv0 + GREEN_LB - 1 < nz ? lv0 + GREEN_LB - 1 : nz;
+  if (k >= 2 && lv1 <= k - 1) return 0;
+  if (lv0 >= k + 2) return 1;
+  return 2;
+}
+
+// The RCE Jacobian's batch as a response problem (ir_green.inc): columns that differ from a base profile in a few
+// temperatures are F(base) + sum of unit responses times Planck differences.  q = (bin - ir_lo) * ng + g.
+struct GreenParams {
+  int nz, ng, n_ir, ir_lo, ir_start, NQ;
+  const double *tau, *w0, *g, *wbin;       // opr (TOA-first layers), g-point weights
+  const double *freq, *ir_freq;            // opacity grid [nw+1], IR channel [nw_ir+1]
+  const double *emissivity;                // [nw_ir]
+  int has_hard_surface;
+  double ir_tau_min;
+  // from the opacities alone (k_green_factor, k_green_unit, k_green_local), all q-major
+  double *RW;                              // [NQ][7][2 nz] per row: c', 1/den, z, running products of phi and of -c' (mantissa, exponent)
+  double *IS;                              // [NQ][6][nz+1]: per level, above form (log, up, down) and below form
+  double *FS;                              // [NQ][2][blocks of 16 levels][34]: the same relative to a block's reference level
+  double *DS;                              // [NQ][10][nz+1]: per k, amplitudes and logs of the two forms, explicit levels
+  // deviations (sorted by k), padded to a multiple of 16
+  int ndev, ndev_pad;
+  const int *dev_k;
+  const double *dev_T, *base_T;            // base_T[k], k TOA-first, k = nz: surface
+  double *DB;                              // [n_ir][ndev_pad]
+  int qsplit;
+  int nmix;                                // (deviation, level block) pairs of mixed class
+  const int *mix_dev, *mix_blk;
+  double *partial;                         // [qsplit][ndev_pad][2][nz+1] (levels TOA-first)
+  // columns
+  const int *col_src, *col_ptr, *col_dev;  // row of gen_out (or -1: base + responses), CSR of a column's deviations
+  const double *gen_out;                   // [3][1 + dense columns][nz+1] (arrays gen_arr apart): column 0 = the base profile
+  size_t gen_arr, out_arr;
+  const double *flux_n;                    // the handle's level rows (solar rows of the last solar call)
+  double *out;                             // [3][ncol][nz+1] (arrays out_arr apart)
+};
+void launch_green_factor(const GreenParams &p, hipStream_t s);
+void launch_green_columns(const GreenParams &p, int ncol, hipStream_t s);
 
 // launchers (kernels.hip)
 void launch_prep(const PrepParams &p, hipStream_t s);

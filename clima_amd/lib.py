@@ -44,6 +44,8 @@ SIGNATURES = {
     "radtran_fused_set": [_vp, _ip],
     "radtran_fused_get": [_vp, _ip],
     "radtran_fused_fallbacks_get": [_vp, _ip],
+    "radtran_ir_green_set": [_vp, _ip],
+    "radtran_ir_green_get": [_vp, _ip, _ip],
     "radtran_coop_items_set": [_vp, _ip],
     "radtran_coop_items_get": [_vp, _ip],
     "radtran_toa_fluxes_batch": [_vp, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _err],

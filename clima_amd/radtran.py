@@ -297,7 +297,7 @@ class Radtran:
             return isr, olr, np.transpose(fl, (2, 1, 0))
         return isr, olr
 
-    def radiate_ir_batch(self, T_surface, T):
+    def radiate_ir_batch(self, T_surface, T, out=None):
         """ncol IR-only calls with the resident opacities in one go: column c is
         `radiate(T_surface[c], T[:, c], ..., compute_solar=False, compute_opacity=False)`
         (the RCE Jacobian's loop, src/adiabat/clima_adiabat_solve.f90:798-812).
@@ -307,7 +307,8 @@ class Radtran:
         if T.ndim != 2 or T.shape[0] != self.nz or T.shape[1] != len(Ts):
             raise ClimaException('"T" has the wrong input dimension.')
         n = T.shape[1]
-        out = [np.empty((self.nz + 1, n), order="F") for _ in range(3)]
+        if out is None:     # (out: three (nz+1, ncol) Fortran-ordered arrays to fill, as a caller that keeps its buffers would)
+            out = [np.empty((self.nz + 1, n), order="F") for _ in range(3)]
         self._L.radtran_radiate_ir_batch(self._ptr, _i(n), _d(Ts), _i(T.shape[0]), _i(n), _d(T),
                                          _d(out[0]), _d(out[1]), _d(out[2]), self._err)
         self._check()
@@ -405,6 +406,25 @@ class Radtran:
     @coop_items.setter
     def coop_items(self, n):
         self._L.radtran_coop_items_set(self._ptr, _i(int(n)))
+
+    @property
+    def ir_green(self):
+        """radiate_ir_batch's response form: 0 never, 1 (default) when enough columns are sparse deviations of one
+        profile, 2 whenever any is."""
+        m, b = C.c_int(), C.c_int()
+        self._L.radtran_ir_green_get(self._ptr, C.byref(m), C.byref(b))
+        return m.value
+
+    @ir_green.setter
+    def ir_green(self, mode):
+        self._L.radtran_ir_green_set(self._ptr, _i(int(mode)))
+
+    @property
+    def ir_green_batches(self):
+        """Batches that took the response form."""
+        m, b = C.c_int(), C.c_int()
+        self._L.radtran_ir_green_get(self._ptr, C.byref(m), C.byref(b))
+        return b.value
 
     @property
     def fused_fallbacks(self):

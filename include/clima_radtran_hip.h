@@ -205,6 +205,16 @@ void radtran_fused_get(void *ptr, int *enabled);
  * (CLIMA_HIP_COOP_ITEMS); 0 turns the group-of-lanes form off.  Same results to rounding (6e-14). */
 void radtran_coop_items_set(void *ptr, const int *items);
 void radtran_coop_items_get(void *ptr, int *items);
+/* radtran_radiate_ir_batch, response form.  With the opacities fixed two_stream_ir
+ * (src/radtran/clima_radtran_twostream.f90:156-295) is linear in the Planck values of the levels, and the columns of
+ * the RCE Jacobian (src/adiabat/clima_adiabat_solve.f90:798-812) are one base profile with one or a few temperatures
+ * changed each: such a column is F(base) + unit responses x Planck differences, which costs one exp and two FMAs per
+ * (level, deviation, bin, g-point) instead of a solve per (column, bin, g-point).  mode 1 (default): taken when at least
+ * 48 columns differ from the batch's majority profile in at most 8 temperatures (the others, and the base profile
+ * itself, go through the general kernel); 0: never; 2: whenever any column qualifies (tests).  CLIMA_HIP_IR_GREEN
+ * sets the default.  Same results to rounding (1e-12 of the level fluxes).  `batches` counts the batches that took it. */
+void radtran_ir_green_set(void *ptr, const int *mode);
+void radtran_ir_green_get(void *ptr, int *mode, int *batches);
 /* A two-stream block of the fused grid waits (bounded) for the opacity blocks of its bin.  If that
  * wait ever expires the call is NOT failed: the library computes it again through the separate
  * launches before results are handed out.  This counts such re-issues on the handle (0 in normal

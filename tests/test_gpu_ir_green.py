@@ -1,0 +1,127 @@
+"""radtran_radiate_ir_batch, response form (clima_amd/csrc/ir_green.inc): columns that differ from the batch's majority
+profile in a few temperatures are F(base) + unit responses x Planck differences.  Held to the oracle's full solves
+(two_stream_ir, src/radtran/clima_radtran_twostream.f90:156-295, one per column as
+src/adiabat/clima_adiabat_solve.f90:798-812 issues them) and to the library's general batch kernel."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_LEVEL = 2.0e-11     # of the row's largest value, as in test_gpu_parity
+
+
+def _scaled(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def _jacobian_batch(col, nz, ncol, rng, extra=True):
+    T = np.repeat(np.asarray(col["T"], dtype=float)[:, None], ncol, axis=1)
+    Ts = np.full(ncol, float(col["T_surface"]))
+    for c in range(ncol):
+        k = c % (nz + 1)
+        dT = 1.0e-2 * (1.0 + rng.random()) * (Ts[c] if k == 0 else T[k - 1, c])
+        if k == 0:
+            Ts[c] += dT
+        else:
+            T[k - 1, c] += dT
+    if extra and ncol >= 8:
+        T[:, 1] = T[:, 1] * (1.0 + 0.01 * rng.random(nz))      # a dense column: every layer moved (general kernel)
+        Ts[2] = float(col["T_surface"]); T[:, 2] = col["T"]      # the base itself
+        for j in (0, nz // 2, nz - 1):                          # three deviations in one column, top and bottom layers among them
+            T[j, 3] += 0.7
+        T[nz - 1, 4] += 0.3; Ts[4] += 0.4                       # top layer and surface
+        T[0, 5] -= 0.5; T[1, 5] += 0.5                          # neighbours
+    return Ts, T
+
+
+@pytest.mark.parametrize("nz,ncol,hard", [(4, 9, True), (5, 12, False), (30, 70, True), (50, 60, False), (64, 20, True),
+                                          (102, 110, True), (130, 30, False), (202, 40, True), (402, 24, True)])
+def test_response_form_against_the_oracle_and_the_general_kernel(O, small_tables, nz, ncol, hard):
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    from test_gpu_parity import _pair, _compare
+    col = S.modern_earth_column(nz)
+    r, o = _pair(O, small_tables, nz, 2, 0.3)
+    r.has_hard_surface = hard
+    o.set_scalars(has_hard_surface=hard)
+    _compare(r, o, col)
+    rng = np.random.default_rng(nz * 1000 + ncol)
+    Ts, T = _jacobian_batch(col, nz, ncol, rng)
+    r.ir_green = 0
+    gen = r.radiate_ir_batch(Ts, T)
+    assert r.ir_green_batches == 0
+    r.ir_green = 2
+    got = r.radiate_ir_batch(Ts, T)
+    assert r.ir_green_batches == 1
+    for a, b in zip(got, gen):
+        for c in range(ncol):
+            assert _scaled(a[:, c], b[:, c]) <= 1.0e-11, (c, _scaled(a[:, c], b[:, c]))
+    for c in range(min(ncol, 14)):
+        w = S.Column(col)
+        w["T"] = T[:, c].copy()
+        w["T_surface"] = Ts[c]
+        o.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+        assert _scaled(got[0][:, c], o.wrk_ir.fup_n) <= TOL_LEVEL
+        assert _scaled(got[1][:, c], o.wrk_ir.fdn_n) <= TOL_LEVEL
+        assert _scaled(got[2][:, c], o.f_total) <= TOL_LEVEL
+
+
+def test_response_form_jacobian_entries(O, small_tables):
+    """What the Jacobian is made of: (F(T + dT) - F(T)) / dT per level.  The response form computes the difference
+    itself instead of subtracting two solves, so its finite differences must agree with the oracle's to the oracle's own
+    cancellation error (~1e-12 |F| / dT after the sums over bins and g-points), here with perturbations of 1e-4 relative."""
+    from clima_amd import synthetic as S
+    from test_gpu_parity import _pair, _compare
+    nz = 60
+    col = S.modern_earth_column(nz)
+    r, o = _pair(O, small_tables, nz, 2, 0.3)
+    _compare(r, o, col)
+    ncol = nz + 2
+    T = np.repeat(np.asarray(col["T"], dtype=float)[:, None], ncol, axis=1)
+    Ts = np.full(ncol, float(col["T_surface"]))
+    dT = np.zeros(ncol)
+    for c in range(1, ncol):
+        k = c - 1
+        if k == 0:
+            dT[c] = 1e-4 * Ts[c]; Ts[c] += dT[c]
+        else:
+            dT[c] = 1e-4 * T[k - 1, c]; T[k - 1, c] += dT[c]
+    r.ir_green = 2
+    fup, fdn, ftot = r.radiate_ir_batch(Ts, T)
+    assert r.ir_green_batches == 1
+    o.radiate(*col.args(), compute_solar=False, compute_opacity=False)
+    base = np.array(o.f_total)
+    for c in (1, 2, nz // 2, nz + 1):
+        w = S.Column(col)
+        w["T"] = T[:, c].copy()
+        w["T_surface"] = Ts[c]
+        o.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+        want = (np.array(o.f_total) - base) / dT[c]
+        have = (ftot[:, c] - ftot[:, 0]) / dT[c]
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(have - want)) <= 1e-7 * scale + 3e-12 * np.max(np.abs(base)) / dT[c]
+
+
+def test_response_form_is_chosen_by_itself_for_a_jacobian_sized_batch(small_tables):
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    nz = 210                                         # (columns x layers >= 20000: below that the general kernel is as fast)
+    col = S.modern_earth_column(nz)
+    r = Radtran(small_tables, nz, 2, 0.3)
+    r.radiate(*col.args())
+    assert r.ir_green == 1
+    rng = np.random.default_rng(3)
+    Ts, T = _jacobian_batch(col, nz, 100, rng)
+    a = r.radiate_ir_batch(Ts, T)
+    assert r.ir_green_batches == 1
+    Ts2, T2 = _jacobian_batch(col, nz, 20, rng)      # too few columns: the general kernel
+    r.radiate_ir_batch(Ts2, T2)
+    assert r.ir_green_batches == 1
+    T3 = T * (1.0 + 0.01 * rng.random(T.shape))       # nothing in common: the general kernel
+    r.radiate_ir_batch(Ts, T3)
+    assert r.ir_green_batches == 1
+    r.ir_green = 0
+    b = r.radiate_ir_batch(Ts, T)
+    for x, y in zip(a, b):
+        assert _scaled(x, y) <= 1e-11
