@@ -1518,7 +1518,7 @@ static void ir_batch_general(Radtran *r, const double *d_T, const double *d_Ts, 
 // The response form (ir_green.inc).  The Jacobian's columns are one base profile with one (on the doubled radiative
 // grid: a few) temperatures changed each; with the opacities fixed the IR solve is linear in the Planck values, so
 // such a column is F(base) + unit responses x Planck differences.  The plan below finds the base (per level the
-// temperature most columns carry: Boyer-Moore vote) and every column's deviations from it; a column with more than
+// temperature two of three sample columns share) and every column's deviations from it; a column with more than
 // GREEN_MAX_DEV of them (the surface-temperature column of a convective profile moves every layer) goes through the
 // general kernel together with the base profile itself.
 constexpr int GREEN_MAX_DEV = 8;
@@ -1530,29 +1530,31 @@ struct GreenPlan {
   int n_sparse = 0;
 };
 static void green_plan(const double *T, const double *Ts, int n, int nz, GreenPlan &pl) {
+  // the base: per level what two of three sample columns agree on (a Jacobian's batch changes a level in one column
+  // only, so any two columns agree nearly everywhere); a poor guess costs speed, never correctness -- columns far from
+  // it go through the general kernel
   pl.base.assign(nz + 1, 0.0);
   {
-    std::vector<int> votes(nz + 1, 0);     // one vote per level, the columns in memory order
-    for (int c = 0; c < n; c++) {
-      const double *Tc = T + (size_t)c * nz;
-      for (int j = 0; j <= nz; j++) {
-        const double v = j < nz ? Tc[j] : Ts[c];
-        if (votes[j] == 0) { pl.base[j] = v; votes[j] = 1; } else if (v == pl.base[j]) votes[j]++; else votes[j]--;
-      }
+    const int c0 = 0, c1 = n / 2, c2 = n - 1;
+    for (int j = 0; j <= nz; j++) {
+      const double a = j < nz ? T[(size_t)c0 * nz + j] : Ts[c0], b = j < nz ? T[(size_t)c1 * nz + j] : Ts[c1],
+                   c = j < nz ? T[(size_t)c2 * nz + j] : Ts[c2];
+      pl.base[j] = (b == c) ? b : a;
     }
   }
   pl.col_src.assign(n, -1);
   std::vector<int> dk, dc; std::vector<double> dT;
+  const double *base = pl.base.data();
   for (int c = 0; c < n; c++) {
     const double *Tc = T + (size_t)c * nz;
-    int found[GREEN_MAX_DEV + 1], cnt = 0;
-    for (int j = 0; j <= nz && cnt <= GREEN_MAX_DEV; j++)
-      if ((j < nz ? Tc[j] : Ts[c]) != pl.base[j]) found[cnt++] = j;
+    int cnt = Ts[c] != base[nz] ? 1 : 0;
+    for (int j = 0; j < nz; j++) cnt += Tc[j] != base[j] ? 1 : 0;      // (no early exit: this loop vectorises)
     if (cnt > GREEN_MAX_DEV) { pl.col_src[c] = 1 + (int)pl.dense.size(); pl.dense.push_back(c); continue; }
     pl.n_sparse++;
-    for (int i = 0; i < cnt; i++) {
-      const int j = found[i];
-      dk.push_back(j < nz ? nz - 1 - j : nz); dc.push_back(c); dT.push_back(j < nz ? Tc[j] : Ts[c]);   // (radiate.f90:65-69: level k is layer nz-1-k)
+    if (cnt == 0) continue;
+    for (int j = 0; j <= nz; j++) {
+      const double v = j < nz ? Tc[j] : Ts[c];
+      if (v != base[j]) { dk.push_back(j < nz ? nz - 1 - j : nz); dc.push_back(c); dT.push_back(v); }   // (radiate.f90:65-69: level k is layer nz-1-k)
     }
   }
   std::vector<int> order(dk.size());

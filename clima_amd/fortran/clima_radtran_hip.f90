@@ -90,6 +90,8 @@ module clima_radtran_hip
     procedure :: comm_init => Radtran_comm_init
     procedure :: comm_init_file => Radtran_comm_init_file
     procedure :: comm_destroy => Radtran_comm_destroy
+    procedure :: set_ir_green => Radtran_set_ir_green
+    procedure :: ir_green_batches => Radtran_ir_green_batches
   end type
 
   interface
@@ -353,6 +355,14 @@ module clima_radtran_hip
     end subroutine
     subroutine c_radtran_comm_destroy(ptr) bind(c, name="radtran_comm_destroy")
       import; type(c_ptr), value :: ptr
+    end subroutine
+    subroutine c_radtran_ir_green_set(ptr, mode) bind(c, name="radtran_ir_green_set")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: mode
+    end subroutine
+    subroutine c_radtran_ir_green_get(ptr, mode, batches) bind(c, name="radtran_ir_green_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(out) :: mode, batches
     end subroutine
     subroutine c_climaradtranwrk_fdn_n_get(ptr, dim1, arr) bind(c, name="climaradtranwrk_fdn_n_get")
       import; type(c_ptr), value :: ptr
@@ -836,5 +846,25 @@ contains
     class(Radtran), intent(inout) :: self
     if (c_associated(self%handle)) call c_radtran_comm_destroy(self%handle)
   end subroutine
+
+  !> `radiate_ir_batch`'s response form (include/clima_radtran_hip.h, radtran_ir_green_set): 0 never, 1 (default) when
+  !> the batch is large and its columns are one profile with a few temperatures changed each -- what
+  !> AdiabatClimate_jacobian_from_base (src/adiabat/clima_adiabat_solve.f90:768-822) issues --, 2 whenever any column is.
+  subroutine Radtran_set_ir_green(self, mode)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: mode
+    if (c_associated(self%handle)) call c_radtran_ir_green_set(self%handle, int(mode, c_int))
+  end subroutine
+
+  !> batches that took the response form so far
+  function Radtran_ir_green_batches(self) result(n)
+    class(Radtran), intent(inout) :: self
+    integer :: n
+    integer(c_int) :: mode, batches
+    n = 0
+    if (.not. c_associated(self%handle)) return
+    call c_radtran_ir_green_get(self%handle, mode, batches)
+    n = batches
+  end function
 
 end module

@@ -155,6 +155,14 @@ program radtran_driver
     Tb(:,1) = T; Tb(:,2) = T; Tb(:,3) = T; Tb(1,3) = T(1) + 1.0_dp
     call rad%radiate_ir_batch(Tsb, Tb, bup, bdn, bft, err); call check()
     write(u,'(es26.17e3)') bft
+    ! ... and in the response form (rad%set_ir_green: columns = one profile + a few changed temperatures)
+    block
+      real(dp) :: gup(nz+1,3), gdn(nz+1,3), gft(nz+1,3)
+      call rad%set_ir_green(2)
+      call rad%radiate_ir_batch(Tsb, Tb, gup, gdn, gft, err); call check()
+      call rad%set_ir_green(1)
+      write(u,'(es26.17e3)') maxval(abs(gft - bft)) / maxval(abs(bft)), real(rad%ir_green_batches(), dp)
+    end block
   end block
 
   ! two independent columns in one batch (the second 1 K warmer): column 1 must reproduce the call above

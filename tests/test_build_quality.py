@@ -19,7 +19,7 @@ from clima_amd import build as B
 
 # kernels of the production paths: fused grid, stand-alone opacity tile, group-of-lanes opacity,
 # wave-per-column two-stream, batched IR, prep, integration
-HOT = re.compile(r"k_fused|k_opacity8|k_opacity_coop|k_twostream_w|k_twostream_h|k_twostream_ir_batch|k_prep|k_integrate_one")
+HOT = re.compile(r"k_fused|k_opacity8|k_opacity_coop|k_twostream_w|k_twostream_h|k_twostream_ir_batch|k_prep|k_integrate_one|k_green_")
 
 
 @pytest.fixture(scope="module")

@@ -37,6 +37,8 @@ def test_fortran_driver_matches_python_and_oracle(O, tmp_path):
     ir_toa = vals[p:p + nw_ir]; p += nw_ir
     sol_toa = vals[p:p + nw_sol]; p += nw_sol
     batch_ft = vals[p:p + 3 * (nz + 1)].reshape(3, nz + 1).T; p += 3 * (nz + 1)
+    green_diff, green_batches = vals[p], vals[p + 1]; p += 2
+    assert green_batches == 1.0 and green_diff <= 1e-11           # rad%set_ir_green(2): the response form, same rows to rounding
     isr_b, olr_b = vals[p:p + 2], vals[p + 2:p + 4]; p += 4
     isr_c, olr_c = vals[p], vals[p + 1]; p += 2
     assert p == len(vals)

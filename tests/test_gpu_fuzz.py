@@ -98,3 +98,53 @@ def test_random_inventory_and_column(O, seed):
         o.set_surface_emissivity(surf[1])
     yard = _yardstick(O, tb, nz, nzen, albedo, col, scalars, surf)
     _compare(r, o, col, flux_tol_scale=max(1.0, 10.0 * yard / TOL_LEVEL))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_ir_batches_in_the_response_form(O, seed):
+    """radtran_radiate_ir_batch: random inventories, columns and batches -- every column a random number (0-11) of
+    random temperature changes of random size on one profile, so sparse and dense columns mix, levels repeat across
+    columns and within the top / bottom rows -- in the response form (ir_green.inc).  Held to the oracle's full solves
+    with the yardstick of this file (the difference between the oracle's two compilations on the same column sets the
+    scale: these columns are badly conditioned on purpose), and the general batch kernel is held to the same."""
+    from clima_amd import synthetic as S
+    from test_gpu_parity import TOL_LEVEL
+    tb, nz, nzen, albedo, col, scalars, rng = _case(5000 + seed)
+    if nz < 4:
+        pytest.skip("fewer than 4 layers: the response form is not taken")
+    r, o = _pair(O, tb, nz, nzen, albedo, **scalars)
+    o2 = O.OracleRadtran(tb, nz, nzen, albedo, variant="fma")
+    o2.set_scalars(**scalars)
+    r.radiate(*col.args())
+    o.radiate(*col.args())
+    o2.radiate(*col.args())
+    ncol = int(rng.integers(2, 40))
+    T = np.repeat(np.asarray(col["T"], dtype=float)[:, None], ncol, axis=1)
+    Ts = np.full(ncol, float(col["T_surface"]))
+    for c in range(ncol):
+        for _ in range(int(rng.integers(0, 12))):
+            j = int(rng.integers(0, nz + 1))
+            d = float(rng.choice([1e-6, 1e-3, 0.1, 3.0, 40.0])) * float(rng.choice([-1.0, 1.0]))
+            if j == nz:
+                Ts[c] += d
+            else:
+                T[j, c] = max(T[j, c] + d, 5.0)
+    r.ir_green = 0
+    gen = r.radiate_ir_batch(Ts, T)
+    r.ir_green = 2
+    got = r.radiate_ir_batch(Ts, T)
+    assert all(np.all(np.isfinite(a)) for a in got)
+    for c in sorted(set(int(x) for x in rng.integers(0, ncol, 4))):
+        w = S.Column(col)
+        w["T"] = T[:, c].copy()
+        w["T_surface"] = Ts[c]
+        want = []
+        for oo in (o, o2):
+            oo.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+            want.append([np.array(oo.wrk_ir.fup_n), np.array(oo.wrk_ir.fdn_n), np.array(oo.f_total)])
+        for i in range(3):
+            scale = max(float(np.max(np.abs(want[0][i]))), 1e-300)
+            yard = float(np.max(np.abs(want[0][i] - want[1][i]))) / scale
+            tol = max(TOL_LEVEL, 10.0 * yard)
+            assert float(np.max(np.abs(got[i][:, c] - want[0][i]))) / scale <= tol, (c, i, "response form")
+            assert float(np.max(np.abs(gen[i][:, c] - want[0][i]))) / scale <= tol, (c, i, "general kernel")

@@ -125,3 +125,66 @@ def test_response_form_is_chosen_by_itself_for_a_jacobian_sized_batch(small_tabl
     b = r.radiate_ir_batch(Ts, T)
     for x, y in zip(a, b):
         assert _scaled(x, y) <= 1e-11
+
+
+@pytest.mark.parametrize("ng,nz", [(4, 50), (12, 70), (16, 130), (32, 40)])
+def test_response_form_at_other_g_point_counts(O, ng, nz):
+    from clima_amd import synthetic as S
+    from test_gpu_parity import _pair
+    tb = S.modern_earth_tables(nw=12, ng=ng, seed=40 + ng)
+    col = S.modern_earth_column(nz)
+    r, o = _pair(O, tb, nz, 2, 0.25)
+    r.radiate(*col.args())
+    o.radiate(*col.args())
+    rng = np.random.default_rng(ng)
+    Ts, T = _jacobian_batch(col, nz, 12, rng)
+    r.ir_green = 2
+    fup, fdn, ftot = r.radiate_ir_batch(Ts, T)
+    assert r.ir_green_batches == 1
+    for c in range(12):
+        w = S.Column(col)
+        w["T"] = T[:, c].copy()
+        w["T_surface"] = Ts[c]
+        o.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+        assert _scaled(fup[:, c], o.wrk_ir.fup_n) <= TOL_LEVEL
+        assert _scaled(fdn[:, c], o.wrk_ir.fdn_n) <= TOL_LEVEL
+        assert _scaled(ftot[:, c], o.f_total) <= TOL_LEVEL
+
+
+def test_response_form_with_extreme_optical_depths(O, small_tables):
+    """Layers that transmit nothing (exp(-lambda tau) underflows to 0: phi = 0 exactly) under layers that are nearly
+    transparent: the running products are held away from 0 and the ratios stay ratios.  Custom optical properties
+    (clima_radtran.f90:494-506) put the thick layers there."""
+    from clima_amd import synthetic as S
+    from test_gpu_parity import _pair
+    nz = 40
+    col = S.modern_earth_column(nz)
+    r, o = _pair(O, small_tables, nz, 2, 0.3)
+    wv = np.geomspace(150.0, 4.0e5, 7)                            # nm
+    P = np.geomspace(1.2e6, 0.5, 6)                               # dynes/cm^2, decreasing
+    dtau_dz = np.repeat((10.0 ** np.linspace(-1.5, -13.0, 6))[:, None], 7, axis=1)   # 1/cm: thousands per layer at the ground
+    w0 = np.full((6, 7), 0.3)
+    g0 = np.full((6, 7), 0.2)
+    for x in (r, o):
+        x.set_custom_optical_properties(wv, P, dtau_dz, w0, g0)
+    r.radiate(*col.args())
+    o.radiate(*col.args())
+    assert np.max(r.opr()[0]) > 2000.0                # exp(-lambda tau) = 0 there
+    rng = np.random.default_rng(5)
+    Ts, T = _jacobian_batch(col, nz, nz + 1, rng, extra=False)
+    r.ir_green = 0
+    gen = r.radiate_ir_batch(Ts, T)
+    r.ir_green = 2
+    got = r.radiate_ir_batch(Ts, T)
+    assert r.ir_green_batches == 1
+    for a, b in zip(got, gen):
+        assert np.all(np.isfinite(a))
+        for c in range(nz + 1):
+            assert _scaled(a[:, c], b[:, c]) <= 1.0e-11, c
+    for c in (0, 1, nz // 2, nz):
+        w = S.Column(col)
+        w["T"] = T[:, c].copy()
+        w["T_surface"] = Ts[c]
+        o.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+        assert _scaled(got[0][:, c], o.wrk_ir.fup_n) <= TOL_LEVEL
+        assert _scaled(got[2][:, c], o.f_total) <= TOL_LEVEL
