@@ -21,6 +21,9 @@
 //   k_twostream_ir_batch  many temperature columns on one set of opacities (the RCE Jacobian,
 //                      src/adiabat/clima_adiabat_solve.f90:798-812): the temperature-independent part once per
 //                      (bin, g-point); blocks of 8 waves up to 256 layers, of 4 (one per SIMD) up to 512.
+//   k_green_*          (ir_green.inc) the same batch as a response problem: columns that are one profile with a few
+//                      temperatures changed = F(profile) + unit responses x Planck differences; what depends on the
+//                      opacities alone once per (bin, g-point), two FMAs per (level, deviation, bin, g-point).
 //   k_fused            the production grid of a compute_opacity call: the opacity tiles of k_opacity8 followed, in
 //                      the SAME launch, by the two-stream blocks of twostream_p_body, each waiting (bounded) for the
 //                      tiles of its bin -- write-through hand-off, no cache-wide fence.

@@ -1674,9 +1674,18 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   if (r->ir_green_mode != 0 && r->batch_shared && nz >= 4 && nz <= 512 && r->ir_n > 0) {   // (CLIMA_HIP_BATCH_SHARED=0: one full solve per column, bit for bit the single call)
     GreenPlan pl;
     green_plan(T, T_surface, n, nz, pl);
-    // worth it from a few dozen sparse columns of a tall grid on (measured: 203 columns x 202 layers 0.78 against 1.28 ms,
+    // worth it from a few dozen sparse columns of a tall grid on (measured: 203 columns x 202 layers 0.60 against 1.29 ms,
     // 103 x 102: 0.54 against 0.46 -- the general kernel's 1-2 slot forms are cheap and the opacity-only pass is not free)
-    green = r->ir_green_mode == 2 ? pl.n_sparse > 0 : (pl.n_sparse >= 48 && (long)pl.n_sparse * nz >= 20000);
+    if (r->ir_green_mode == 2) green = pl.n_sparse > 0;
+    else if (pl.n_sparse >= 48) {
+      // cost model (ms on an MI355X, from profiles/r03_ir_batch.txt and the rocprofv3 runs behind DESIGN section 4; both
+      // sides scale with the number of (bin, g-point) pairs): the general kernel per column against the opacity-only
+      // pass + the accumulation over deviations x levels + the extra launches
+      const double scale = (double)r->ir_n * r->ng / 4800.0;
+      const double t_general = pl.n_sparse * (nz <= 256 ? 0.032e-3 : 0.044e-3) * nz * scale;
+      const double t_green = 0.05 + scale * (0.35 * nz / 402.0 + 0.56 * (double)pl.dev_k.size() * nl / 162409.0);
+      green = t_green < 0.8 * t_general;
+    }
     if (green) ir_batch_green(r, pl, T, T_surface, n, r->d_bout.p);
   }
   if (!green) {

@@ -210,7 +210,7 @@ void radtran_coop_items_get(void *ptr, int *items);
  * the RCE Jacobian (src/adiabat/clima_adiabat_solve.f90:798-812) are one base profile with one or a few temperatures
  * changed each: such a column is F(base) + unit responses x Planck differences, which costs one exp and two FMAs per
  * (level, deviation, bin, g-point) instead of a solve per (column, bin, g-point).  mode 1 (default): taken when at least
- * 48 columns differ from the profile the batch's columns share in at most 8 temperatures and columns x layers >= 20000 (the others, and the base profile
+ * 48 columns differ from the profile the batch's columns share in at most 8 temperatures and a cost model of the two forms favours it -- tall grids, few changes per column -- (the others, and the base profile
  * itself, go through the general kernel); 0: never; 2: whenever any column qualifies (tests).  CLIMA_HIP_IR_GREEN
  * sets the default.  Same results to rounding (1e-12 of the level fluxes).  `batches` counts the batches that took it. */
 void radtran_ir_green_set(void *ptr, const int *mode);

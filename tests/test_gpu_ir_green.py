@@ -103,12 +103,12 @@ def test_response_form_jacobian_entries(O, small_tables):
         assert np.max(np.abs(have - want)) <= 1e-7 * scale + 3e-12 * np.max(np.abs(base)) / dT[c]
 
 
-def test_response_form_is_chosen_by_itself_for_a_jacobian_sized_batch(small_tables):
+def test_response_form_is_chosen_by_itself_for_a_jacobian_sized_batch():
     from clima_amd import synthetic as S
     from clima_amd.radtran import Radtran
-    nz = 210                                         # (columns x layers >= 20000: below that the general kernel is as fast)
+    nz = 210                                         # (a small spectrum or a short grid: the general kernel is as fast)
     col = S.modern_earth_column(nz)
-    r = Radtran(small_tables, nz, 2, 0.3)
+    r = Radtran(S.modern_earth_tables(nw=400), nz, 2, 0.3)
     r.radiate(*col.args())
     assert r.ir_green == 1
     rng = np.random.default_rng(3)
@@ -117,6 +117,11 @@ def test_response_form_is_chosen_by_itself_for_a_jacobian_sized_batch(small_tabl
     assert r.ir_green_batches == 1
     Ts2, T2 = _jacobian_batch(col, nz, 20, rng)      # too few columns: the general kernel
     r.radiate_ir_batch(Ts2, T2)
+    assert r.ir_green_batches == 1
+    Ts4, T4 = Ts.copy(), T.copy()                    # eight changes per column: the accumulation would cost more than it saves
+    for c in range(T4.shape[1]):
+        T4[rng.integers(0, nz, 7), c] += 0.25
+    r.radiate_ir_batch(Ts4, T4)
     assert r.ir_green_batches == 1
     T3 = T * (1.0 + 0.01 * rng.random(T.shape))       # nothing in common: the general kernel
     r.radiate_ir_batch(Ts, T3)
