@@ -1686,6 +1686,10 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
       const double t_green = 0.05 + scale * (0.35 * nz / 402.0 + 0.56 * (double)pl.dev_k.size() * nl / 162409.0);
       green = t_green < 0.8 * t_general;
     }
+    // not with a base that is not a number anywhere (every column would "deviate" there and inherit it), nor when the
+    // work arrays (~150 KB per (bin, g-point) at 500 layers) would take more than 16 GB
+    for (double v : pl.base) if (!std::isfinite(v)) green = false;
+    if ((double)r->ir_n * r->ng * (13.0 * nl + 14.0 * nz + 4.3 * nl) * 8.0 > 16.0e9) green = false;
     if (green) ir_batch_green(r, pl, T, T_surface, n, r->d_bout.p);
   }
   if (!green) {

@@ -193,3 +193,26 @@ def test_response_form_with_extreme_optical_depths(O, small_tables):
         o.radiate(*w.args(), compute_solar=False, compute_opacity=False)
         assert _scaled(got[0][:, c], o.wrk_ir.fup_n) <= TOL_LEVEL
         assert _scaled(got[2][:, c], o.f_total) <= TOL_LEVEL
+
+
+def test_a_profile_that_is_not_a_number_stays_with_the_general_kernel(small_tables):
+    """NaN in the shared profile: every column would "deviate" at that level and inherit it from the base solve; the
+    general kernel confines it to the columns that carry it."""
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    nz = 30
+    col = S.modern_earth_column(nz)
+    r = Radtran(small_tables, nz, 2, 0.3)
+    r.radiate(*col.args())
+    rng = np.random.default_rng(2)
+    Ts, T = _jacobian_batch(col, nz, 12, rng, extra=False)
+    T[5, :] = np.nan
+    r.ir_green = 2
+    r.radiate_ir_batch(Ts, T)
+    assert r.ir_green_batches == 0
+    T[5, :] = col["T"][5]
+    T[5, 3] = np.nan                                   # one column only: a deviation like any other
+    a = r.radiate_ir_batch(Ts, T)
+    assert r.ir_green_batches == 1
+    assert np.all(np.isnan(a[0][:, 3])) or np.any(np.isnan(a[0][:, 3]))
+    assert np.all(np.isfinite(np.delete(a[0], 3, axis=1)))
