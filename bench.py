@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--nzen", type=int, default=None)
     ap.add_argument("--ncol", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-jacobian", action="store_true", help="skip the RCE-Jacobian batch figure (rce_jacobian_batch)")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: anything libraries print there (RCCL's version
@@ -264,6 +265,36 @@ def main():
         sync_api = _stats(np.array(ts) * 1e6, "the same call through the ctypes mirror clima_amd.radtran.Radtran.TOA_fluxes")
         rad.upload_column(*a)
 
+    # ---- companion figure (not `value`): the RCE Jacobian's batch on this column's grid -- nz+1 IR-only
+    # calls on the resident opacities, each with one temperature changed, through radtran_radiate_ir_batch: the general
+    # batch kernel and the response form the library takes for such a batch by itself
+    jac = None
+    if not dist_on and cfg in (2, 3, 5) and not args.no_jacobian:
+        ncj = nz + 1
+        Tj = np.repeat(np.asarray(col["T"], dtype=float)[:, None], ncj, axis=1)
+        Tsj = np.full(ncj, float(col["T_surface"]))
+        Tsj[0] += 1.0
+        for c in range(1, ncj):
+            Tj[c - 1, c] += 1.0
+        jres = {}
+        for mode in (0, 1):
+            rad.ir_green = mode
+            n0 = rad.ir_green_batches
+            outj = rad.radiate_ir_batch(Tsj, Tj)
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                rad.radiate_ir_batch(Tsj, Tj, out=outj)
+                best = min(best, time.perf_counter() - t0)
+            jres[mode] = (best, [np.array(x) for x in outj], rad.ir_green_batches > n0)
+        rad.ir_green = 1
+        dj = max(float(np.max(np.abs(x - y)) / np.max(np.abs(y))) for x, y in zip(jres[1][1], jres[0][1]))
+        jac = {"what": "radtran_radiate_ir_batch: %d IR-only columns x %d layers on the resident opacities, one temperature changed "
+                       "per column (src/adiabat/clima_adiabat_solve.f90:798-812), host arrays in and out, best of 3" % (ncj, nz),
+               "ms": 1e3 * jres[1][0], "us_per_column": 1e6 * jres[1][0] / ncj, "response_form": bool(jres[1][2]),
+               "general_kernel_ms": 1e3 * jres[0][0], "largest_difference_of_row_maximum": dj}
+        rad.upload_column(*a)
+
     # ---- companion figure for N > 1 (not `value`): the column-parallel form of config 4 --
     # every rank runs whole, unsharded calls on its own column, no collective (weak scaling)
     col_par = None
@@ -367,6 +398,8 @@ def main():
             out["sync_api"] = sync_api
         if col_par is not None:
             out["column_parallel"] = col_par
+        if jac is not None:
+            out["rce_jacobian_batch"] = jac
         if not args.no_cpu_baseline:   # rank 0, every N (the other ranks wait at the final barrier)
             out.update(cpu_baseline(tables, col, nz, nzen, albedo, olr, rad if world == 1 else None, 0.4286 if cfg == 3 else None))
         sys.stdout.flush()
