@@ -2414,6 +2414,67 @@ void clima_test_two_stream(const int *nz_, const int *ng_, const int *form, cons
   CATCH(err)
 }
 
+// Test hook of the response form (ir_green.inc), the counterpart of clima_test_two_stream for it: one column's tau / w0 /
+// g (the same for every g-point, weights wbin) and ndev deviations (level k TOA-first, k = nz the surface; change of the
+// Planck value there) -> per deviation the change of the level fluxes (TOA-first), sum over the g-points, exactly as the
+// production kernels form it (k_green_factor / unit / local / accum_far / accum_mixed); only the Planck differences come
+// from the caller instead of k_green_db.
+void clima_test_ir_response(const int *nz_, const int *ng_, const double *tau, const double *w0, const double *g,
+                            const double *ir_par, const double *wbin, const int *ndev_, const int *dev_k,
+                            const double *dev_db, double *resp_up, double *resp_dn, char *err) {
+  clear_err(err);
+  TRY
+  const int nz = *nz_, ng = *ng_, nl = nz + 1, N = 2 * nz, ndev = *ndev_;
+  if (nz < 4 || ng < 1 || ng > 32 || ndev < 1) throw HipFail{"clima_test_ir_response: bad nz / ng / ndev"};
+  std::vector<int> order(ndev);
+  for (int i = 0; i < ndev; i++) { order[i] = i; if (dev_k[i] < 0 || dev_k[i] > nz) throw HipFail{"clima_test_ir_response: bad level"}; }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dev_k[a] < dev_k[b]; });
+  const int ndev_pad = std::max(16, (ndev + 15) / 16 * 16), nblk = (nl + 15) / 16;
+  std::vector<double> h_tau((size_t)ng * nz), h_w0((size_t)ng * nz), h_db(ndev_pad, 0.0);
+  for (int c = 0; c < ng; c++)
+    for (int i = 0; i < nz; i++) { h_tau[(size_t)c * nz + i] = tau[i]; h_w0[(size_t)c * nz + i] = w0[i]; }
+  std::vector<int> hi(ndev_pad, 0), mdev, mblk;
+  for (int d = 0; d < ndev; d++) { hi[d] = dev_k[order[d]]; h_db[d] = dev_db[order[d]]; }
+  for (int d = 0; d < ndev; d++)
+    for (int blk = 0; blk < nblk; blk++)
+      if (green_block_class(hi[d], blk, nz) == 2) { mdev.push_back(d); mblk.push_back(blk); }
+  const int nmix = (int)mdev.size();
+  hi.insert(hi.end(), mdev.begin(), mdev.end());
+  hi.insert(hi.end(), mblk.begin(), mblk.end());
+  DevBuf<double> d_tau, d_w0, d_g, d_wbin, d_em, d_db, d_work;
+  DevBuf<int> d_idx;
+  d_tau.upload(h_tau); d_w0.upload(h_w0); d_g.upload(std::vector<double>(g, g + nz));
+  d_wbin.upload(std::vector<double>(wbin, wbin + ng)); d_em.upload(std::vector<double>{ir_par[0]});
+  d_db.upload(h_db); d_idx.upload(hi);
+  const size_t RQ = (size_t)N * ng, LQ = (size_t)nl * ng, FQ = (size_t)2 * nblk * 34 * ng;
+  d_work.alloc(7 * RQ + 6 * LQ + FQ + 10 * LQ + (size_t)ndev_pad * 2 * nl); d_work.zero();
+  GreenParams gp;
+  std::memset(&gp, 0, sizeof(gp));
+  gp.nz = nz; gp.ng = ng; gp.n_ir = 1; gp.ir_lo = 0; gp.ir_start = 0; gp.NQ = ng;
+  gp.tau = d_tau.p; gp.w0 = d_w0.p; gp.g = d_g.p; gp.wbin = d_wbin.p; gp.emissivity = d_em.p;
+  gp.has_hard_surface = ir_par[1] != 0.0 ? 1 : 0; gp.ir_tau_min = ir_par[2];
+  double *w = d_work.p;
+  auto take = [&](size_t cnt) { double *p0 = w; w += cnt; return p0; };
+  gp.RW = take(7 * RQ); gp.IS = take(6 * LQ); gp.FS = take(FQ); gp.DS = take(10 * LQ);
+  gp.partial = take((size_t)ndev_pad * 2 * nl);
+  gp.DB = d_db.p;
+  gp.ndev = ndev; gp.ndev_pad = ndev_pad; gp.qsplit = 1;
+  gp.dev_k = d_idx.p; gp.nmix = nmix; gp.mix_dev = gp.dev_k + ndev_pad; gp.mix_blk = gp.mix_dev + nmix;
+  launch_green_factor(gp, nullptr);
+  HIPCHK(hipGetLastError());
+  launch_green_accumulate(gp, nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<double> out((size_t)ndev_pad * 2 * nl);
+  HIPCHK(hipMemcpy(out.data(), gp.partial, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
+  for (int d = 0; d < ndev; d++)
+    for (int lv = 0; lv < nl; lv++) {
+      resp_up[(size_t)order[d] * nl + lv] = out[((size_t)d * 2 + 0) * nl + lv];
+      resp_dn[(size_t)order[d] * nl + lv] = out[((size_t)d * 2 + 1) * nl + lv];
+    }
+  CATCH(err)
+}
+
 // ---- reference-named getters / setters (clima/fortran/Radtran.f90) -------------------
 
 static double bolometric(Radtran *r) {  // Radtran_bolometric_flux, clima_radtran.f90:353-364

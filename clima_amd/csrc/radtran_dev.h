@@ -314,6 +314,7 @@ struct GreenParams {
 };
 void launch_green_factor(const GreenParams &p, hipStream_t s);
 void launch_green_columns(const GreenParams &p, int ncol, hipStream_t s);
+void launch_green_accumulate(const GreenParams &p, hipStream_t s);   // the accumulation alone (test hook: DB given)
 
 // launchers (kernels.hip)
 void launch_prep(const PrepParams &p, hipStream_t s);

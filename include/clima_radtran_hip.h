@@ -276,6 +276,15 @@ void clima_test_two_stream(const int *nz, const int *ng, const int *form, const 
                            const double *w0, const double *g, const double *bplanck, const double *ir_par,
                            const double *sol_par, const double *wbin, double *ir_fup, double *ir_fdn,
                            double *sol_fup, double *sol_fdn, double *sol_amean, char *err);
+/* The same for the response form of radtran_radiate_ir_batch (ir_green.inc): the column of clima_test_two_stream and
+ * `ndev` changes of the Planck value at levels dev_k (TOA-first, nz = the surface) -> per change the change of the level
+ * fluxes, resp_up / resp_dn (nz+1, ndev) TOA-first, summed over the g-points with the weights wbin -- produced by the
+ * production kernels (k_green_factor, k_green_unit, k_green_local, k_green_accum_far, k_green_accum_mixed).
+ * tests/test_gpu_golden.py holds F(base) + the changes to what the reference's two_stream_ir
+ * (src/radtran/clima_radtran_twostream.f90:156-295) returns for the changed Planck profile.  nz >= 4. */
+void clima_test_ir_response(const int *nz, const int *ng, const double *tau, const double *w0, const double *g,
+                            const double *ir_par, const double *wbin, const int *ndev, const int *dev_k,
+                            const double *dev_db, double *resp_up, double *resp_dn, char *err);
 
 /* OpticalPropertiesResult (clima_radtran_types.f90:242-247), for parity checks:
  * tau,w0 (nz,ngauss,nw) and g,tau_band (nz,nw), column-major, TOA-first. */

@@ -16,6 +16,8 @@ Cases 36-67: smooth Planck profiles and pressure-like optical depths (the shape 
 nz = 1 ... 512, including every chunk edge of the 64-lane decomposition.
 Cases 68-89: the same kind of column with pairwise identical layers (the doubled radiative grid of
 AdiabatClimate), nz = 2 ... 512 even, for the paired kernel instantiations.
+Response cases r00...: smooth and paired cases again with a few of their Planck values changed (a column of the RCE
+Jacobian against its base profile), for the response form of the batched IR call.
 """
 import os
 import sys
@@ -122,6 +124,32 @@ def main():
                         k + "sol_fup": sfup, k + "sol_fdn": sfdn})
             n += 1
     out["ncases"] = np.array([n])
+    # ---- response cases r00...: a smooth case above with a FEW of its Planck values changed (what a column of the RCE
+    # Jacobian is to the base profile, src/adiabat/clima_adiabat_solve.f90:798-812): the reference's two_stream_ir on
+    # the changed profile.  Levels next to the top and the surface, neighbours, several per column; changes of 3 %
+    # (a few K) and of 1e-4 relative.  tests/test_gpu_golden.py holds F(base) + the response form's changes to these.
+    rng4 = np.random.default_rng(20261101)
+    m = 0
+    for base in range(36, n):
+        nz = len(out["c%02d_tau" % base])
+        if nz < 4 or (base % 2 == 1 and nz not in (5, 65, 129, 257, 402)):
+            continue
+        k = "c%02d_" % base
+        tau, w0, g, bp, par = (out[k + x] for x in ("tau", "w0", "g", "bplanck", "ir_par"))
+        cols = [[0], [1], [nz], [nz - 1], [nz // 2], [0, nz], [nz // 3, nz // 3 + 1], [2, nz // 2, nz - 2],
+                sorted(set(int(x) for x in rng4.integers(0, nz + 1, 3)))]
+        r = "r%02d_" % m
+        out[r + "base"] = np.array([base])
+        out[r + "ncol"] = np.array([len(cols)])
+        for j, ks in enumerate(cols):
+            rel = 1e-4 if j % 3 == 2 else 0.03
+            bp2 = bp.copy()
+            for kk in ks:
+                bp2[kk] = bp[kk] * (1.0 + rel * (1.0 + rng4.random()))
+            fup2, fdn2 = O.ref_two_stream_ir(tau, w0, g, float(par[0]), bool(par[1]), float(par[2]), bp2)
+            out.update({r + "c%d_k" % j: np.array(ks), r + "c%d_b" % j: bp2[ks], r + "c%d_fup" % j: fup2, r + "c%d_fdn" % j: fdn2})
+        m += 1
+    out["nresp"] = np.array([m])
     path = os.path.join(HERE, "twostream_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, n, "cases", os.path.getsize(path), "bytes")

@@ -30,6 +30,23 @@ def test_golden_two_stream_ir(O):
         assert fdn[0] == 0.0 == d[k + "ir_fdn"][0]
 
 
+def test_golden_two_stream_ir_changed_profiles(O):
+    """The response cases: 31 of the smooth / paired columns with a few Planck values changed each (279 profiles)."""
+    d = np.load(GOLD)
+    nresp = int(d["nresp"][0])
+    assert nresp >= 25
+    for m in range(nresp):
+        r = "r%02d_" % m
+        k = "c%02d_" % int(d[r + "base"][0])
+        em, hs, tmin = d[k + "ir_par"]
+        for j in range(int(d[r + "ncol"][0])):
+            bp = d[k + "bplanck"].copy()
+            bp[d[r + "c%d_k" % j]] = d[r + "c%d_b" % j]
+            fup, fdn = O.two_stream_ir(d[k + "tau"], d[k + "w0"], d[k + "g"], em, bool(hs), tmin, bp)
+            assert _rel(fup, d[r + "c%d_fup" % j]) <= RTOL, (m, j)
+            assert _rel(fdn[1:], d[r + "c%d_fdn" % j][1:]) <= RTOL, (m, j)
+
+
 def test_golden_two_stream_solar(O):
     d = np.load(GOLD)
     for n in range(int(d["ncases"][0])):
