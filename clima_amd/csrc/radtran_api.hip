@@ -1663,8 +1663,9 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   if (r->state != 2) { set_err(err, "Radtran is not constructed"); return; }
   if (*dim1_T != r->nz || *dim2_T != *ncol || *ncol < 1) { set_err(err, "\"T\" has the wrong input dimension."); return; }
   if (!r->opr_valid) { set_err(err, "radiate_ir_batch needs opacities: call radiate with compute_opacity first"); return; }
-  if (r->shard_world != 1) { set_err(err, "radiate_ir_batch is not available on a bin-sharded handle"); return; }
+  if (r->shard_world != 1 && !r->comm) { set_err(err, "radiate_ir_batch is not available on a bin-sharded handle"); return; }
   TRY
+  settle(r);          // (a communicator handle: the level rows of the last step are the reduced ones from here on)
   upload_fields(r);
   ensure_w0(r);
   const int nz = r->nz, nl = nz + 1, n = *ncol;
@@ -1698,8 +1699,16 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     HIPCHK(hipMemcpyAsync(r->d_bTs.p, T_surface, sizeof(double) * n, hipMemcpyHostToDevice, r->stream));
     ir_batch_general(r, r->d_bT.p, r->d_bTs.p, n, r->d_bout.p, (size_t)n * nl);
   }
-  // the three result arrays come back through the handle's pinned block
   const size_t arr = (size_t)n * nl;
+  if (r->comm) {
+    // a communicator handle worked on its share of the bins: one all-reduce of the batch's up / down arrays
+    // (src/radtran/clima_radtran_radiate.f90:184-192 summed over the bins of all ranks), f_total from the reduced rows
+    NCCLCHK(ncclAllReduce(r->d_bout.p, r->d_bout.p, 2 * arr, ncclDouble, ncclSum, r->comm, r->stream));
+    r->comm_reduces++;
+    launch_batch_ftotal(r->d_bout.p, arr, n, nz, r->d_flux_n.p, r->stream);
+    HIPCHK(hipGetLastError());
+  }
+  // the three result arrays come back through the handle's pinned block
   if (r->h_bout_n < 3 * arr) {
     if (r->h_bout) (void)hipHostFree(r->h_bout);
     r->h_bout = nullptr; r->h_bout_n = 0;

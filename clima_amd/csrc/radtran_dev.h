@@ -314,6 +314,7 @@ struct GreenParams {
 };
 void launch_green_factor(const GreenParams &p, hipStream_t s);
 void launch_green_columns(const GreenParams &p, int ncol, hipStream_t s);
+void launch_batch_ftotal(double *out, size_t out_arr, int ncol, int nz, const double *flux_n, hipStream_t s);
 void launch_green_accumulate(const GreenParams &p, hipStream_t s);   // the accumulation alone (test hook: DB given)
 
 // launchers (kernels.hip)

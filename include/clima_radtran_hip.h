@@ -178,7 +178,10 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
  * compute_solar = compute_opacity = .false.).  T is (nz, ncol) column-major, T_surface (ncol);
  * column c receives that call's wrk_ir%fup_n, wrk_ir%fdn_n and f_total in (nz+1, ncol) arrays.
  * Uses the opacities of the last compute_opacity call and the solar fluxes of the last solar
- * call; the handle's own wrk_ir / f_total are left untouched. */
+ * call; the handle's own wrk_ir / f_total are left untouched.  On a handle with a communicator
+ * (radtran_comm_init_rank) every rank passes the same columns, works on its share of the bins and the library
+ * all-reduces the batch's up / down arrays once (2 (nz+1) ncol doubles) before f_total is formed: every rank
+ * receives the whole result.  A bin shard without a communicator (radtran_set_bin_shard) is refused. */
 void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
                               const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
                               double *f_total, char *err);

@@ -196,3 +196,53 @@ def test_radiation_enhancement_on_a_communicator_handle(hip_lib, small_tables):
     np.testing.assert_allclose(got_sol, want_sol, rtol=1e-13)      # the enhanced partial rows were put back
     got_f = sum(np.array(p.f_total) for p in parts)
     np.testing.assert_allclose(got_f, np.array(ref.f_total), rtol=1e-12, atol=1e-12 * np.max(np.abs(want_f)))
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_ir_batch_on_communicator_handles(hip_lib, small_tables, mode):
+    """radtran_radiate_ir_batch (the RCE Jacobian's batch) on a handle with a communicator: the rank's share of the bins
+    -> ONE all-reduce of the batch's up / down arrays -> f_total from the reduced rows.  One rank: bit for bit the plain
+    call; three rehearsed shards: their rows add up to it.  General kernel (mode 0) and response form (mode 2)."""
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    nz, W, ncol = 60, 3, 14
+    col = S.modern_earth_column(nz)
+    T = np.repeat(np.asarray(col["T"], dtype=float)[:, None], ncol, axis=1)
+    Ts = np.full(ncol, float(col["T_surface"]))
+    Ts[0] += 1.0
+    for c in range(1, ncol):
+        T[(5 * c) % nz, c] += 0.5 + 0.1 * c
+    T[:, 3] += np.linspace(0.0, 2.0, nz)                           # a dense column
+    ref = Radtran(small_tables, nz, 2, 0.2)
+    ref.ir_green = mode
+    ref.radiate(*col.args())
+    want = ref.radiate_ir_batch(Ts, T)
+
+    one = Radtran(small_tables, nz, 2, 0.2)
+    one.ir_green = mode
+    one.comm_init_rank(1, 0, Radtran.comm_unique_id())
+    one.radiate(*col.args())
+    n0 = one.comm()[2]
+    got = one.radiate_ir_batch(Ts, T)
+    assert one.comm()[2] == n0 + 1                                 # exactly one collective per batch
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(np.array(one.f_total), np.array(ref.f_total))   # the handle's own state is untouched
+
+    parts = []
+    for k in range(W):
+        r = Radtran(small_tables, nz, 2, 0.2)
+        r.ir_green = mode
+        r.comm_init_rank(1, 0, Radtran.comm_unique_id())
+        r.set_bin_shard(k, W)
+        r.radiate(*col.args())
+        parts.append(r.radiate_ir_batch(Ts, T))
+    for i in range(3):
+        s = sum(p[i] for p in parts)
+        np.testing.assert_allclose(s, want[i], rtol=1e-12, atol=1e-12 * np.max(np.abs(want[i])))
+    plain = Radtran(small_tables, nz, 2, 0.2)
+    plain.set_bin_shard(0, 2)                                       # a shard without a communicator: nobody would reduce
+    plain.radiate(*col.args())
+    from clima_amd.radtran import ClimaException
+    with pytest.raises(ClimaException, match="bin-sharded"):
+        plain.radiate_ir_batch(Ts, T)
