@@ -1630,7 +1630,8 @@ static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, con
   // waves more than that and the kernel takes two rounds
   const int qsplit = std::max(1, std::min(std::min(n_ir, 64), 2900 / std::max(waves, 1)));
   const size_t FQ = (size_t)2 * ((nl + 15) / 16) * 34 * NQ;    // (GREEN_LB, GREEN_FS of ir_green.inc)
-  const size_t total = 7 * RQ + 6 * LQ + FQ + 10 * LQ + (size_t)n_ir * ndev_pad + (size_t)qsplit * ndev_pad * 2 * nl;
+  const int msplit = std::max(qsplit, std::min(n_ir, 4096 / std::max((nmix + 3) / 4, 1)));   // the mixed blocks: few pairs, finer splits
+  const size_t total = 7 * RQ + 6 * LQ + FQ + 10 * LQ + (size_t)n_ir * ndev_pad + (size_t)(qsplit + msplit) * ndev_pad * 2 * nl;
   ensure(r->d_green, total);
   GreenParams g;
   std::memset(&g, 0, sizeof(g));
@@ -1643,6 +1644,7 @@ static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, con
   g.RW = take(7 * RQ);
   g.IS = take(6 * LQ); g.FS = take(FQ); g.DS = take(10 * LQ);
   g.DB = take((size_t)n_ir * ndev_pad); g.partial = take((size_t)qsplit * ndev_pad * 2 * nl);
+  g.msplit = msplit; g.partial_m = take((size_t)msplit * ndev_pad * 2 * nl);
   g.ndev = ndev; g.ndev_pad = ndev_pad; g.qsplit = qsplit;
   g.dev_k = r->d_green_idx.p; g.col_src = g.dev_k + ndev_pad; g.col_ptr = g.col_src + n; g.col_dev = g.col_ptr + n + 1;
   g.nmix = nmix; g.mix_dev = g.col_dev + ndev; g.mix_blk = g.mix_dev + nmix;
@@ -2467,7 +2469,7 @@ void clima_test_ir_response(const int *nz_, const int *ng_, const double *tau, c
   gp.RW = take(7 * RQ); gp.IS = take(6 * LQ); gp.FS = take(FQ); gp.DS = take(10 * LQ);
   gp.partial = take((size_t)ndev_pad * 2 * nl);
   gp.DB = d_db.p;
-  gp.ndev = ndev; gp.ndev_pad = ndev_pad; gp.qsplit = 1;
+  gp.ndev = ndev; gp.ndev_pad = ndev_pad; gp.qsplit = 1; gp.msplit = 1; gp.partial_m = gp.partial;   // (disjoint pairs: one array)
   gp.dev_k = d_idx.p; gp.nmix = nmix; gp.mix_dev = gp.dev_k + ndev_pad; gp.mix_blk = gp.mix_dev + nmix;
   launch_green_factor(gp, nullptr);
   HIPCHK(hipGetLastError());

@@ -305,6 +305,8 @@ struct GreenParams {
   int nmix;                                // (deviation, level block) pairs of mixed class
   const int *mix_dev, *mix_blk;
   double *partial;                         // [qsplit][ndev_pad][2][nz+1] (levels TOA-first)
+  int msplit;                              // bin splits of the mixed blocks' kernel
+  double *partial_m;                       // [msplit][ndev_pad][2][nz+1]: its sums (only the mixed (deviation, level) pairs are written)
   // columns
   const int *col_src, *col_ptr, *col_dev;  // row of gen_out (or -1: base + responses), CSR of a column's deviations
   const double *gen_out;                   // [3][1 + dense columns][nz+1] (arrays gen_arr apart): column 0 = the base profile
