@@ -698,25 +698,22 @@ contains
   !> leave in `self%f_total`, `fup_n`/`fdn_n` what it would leave in `self%wrk_ir`.
   subroutine Radtran_radiate_ir_batch(self, T_surface, T, fup_n, fdn_n, f_total, err)
     class(Radtran), intent(inout) :: self
-    real(dp), intent(in) :: T_surface(:)   !! (ncol)
-    real(dp), intent(in) :: T(:,:)         !! (nz, ncol)
-    real(dp), intent(out) :: fup_n(:,:), fdn_n(:,:), f_total(:,:)   !! (nz+1, ncol)
+    real(dp), intent(in), contiguous :: T_surface(:)   !! (ncol)
+    real(dp), intent(in), contiguous :: T(:,:)         !! (nz, ncol)
+    real(dp), intent(out), contiguous :: fup_n(:,:), fdn_n(:,:), f_total(:,:)   !! (nz+1, ncol)
     character(:), allocatable, intent(out) :: err
     character(c_char) :: err_c(err_len+1)
-    real(dp), allocatable :: Tc(:,:), a(:,:), b(:,:), c(:,:)
     integer :: ncol
+    ! (`contiguous`: the arrays go to the library as they are -- the batch is ~1 ms, copies of 1-4 MB would show; a
+    ! strided actual argument is copied in / out by the compiler)
     ncol = size(T_surface)
     if (size(T,2) /= ncol .or. any(shape(fup_n) /= [self%nz+1, ncol]) .or. &
         any(shape(fdn_n) /= [self%nz+1, ncol]) .or. any(shape(f_total) /= [self%nz+1, ncol])) then
       err = '"T" has the wrong input dimension.'
       return
     endif
-    Tc = T
-    allocate(a(self%nz+1,ncol), b(self%nz+1,ncol), c(self%nz+1,ncol))
-    call c_radtran_radiate_ir_batch(self%handle, ncol, T_surface, size(Tc,1), size(Tc,2), Tc, a, b, c, err_c)
+    call c_radtran_radiate_ir_batch(self%handle, ncol, T_surface, size(T,1), size(T,2), T, fup_n, fdn_n, f_total, err_c)
     call take_err(err_c, err)
-    if (allocated(err)) return
-    fup_n = a; fdn_n = b; f_total = c
   end subroutine
 
   !> clima_radtran.f90 `opacities2yaml` (-> clima_radtran_types.f90:328-430)

@@ -112,6 +112,11 @@ program radtran_driver
       call rad%destroy()
       stop
     endif
+    if (trim(arg) == 'jac') then
+      call time_jacobian()
+      call rad%destroy()
+      stop
+    endif
   endif
 
   ! tests/test_radtran.f90:67
@@ -217,6 +222,58 @@ program radtran_driver
   call rad%destroy()
 
 contains
+  ! `radtran_driver case.bin out.txt jac`: the RCE Jacobian's radiative work as a Fortran host issues it
+  ! (src/adiabat/clima_adiabat_solve.f90:798-812): one full call, then nz+1 IR-only columns with one temperature changed
+  ! each -- through rad%radiate_ir_batch (general kernel and response form) and one rad%radiate at a time
+  subroutine time_jacobian()
+    use iso_fortran_env, only: int64
+    integer(int64) :: c0, c1, rate
+    real(dp), allocatable :: Tsb(:), Tb(:,:), bup(:,:), bdn(:,:), bft(:,:), gft(:,:)
+    real(dp) :: best(2), t_loop
+    integer :: c, rep, mode
+    if (np > 0) then
+      call rad%radiate(T_surface, T, P, densities, dz, pdensities, radii, err=err)
+    else
+      call rad%radiate(T_surface, T, P, densities, dz, err=err)
+    endif
+    call check()
+    allocate(Tsb(nz+1), Tb(nz,nz+1), bup(nz+1,nz+1), bdn(nz+1,nz+1), bft(nz+1,nz+1), gft(nz+1,nz+1))
+    Tsb = T_surface; Tsb(1) = T_surface + 1.0_dp
+    do c = 2, nz + 1
+      Tb(:,c) = T; Tb(c-1,c) = T(c-1) + 1.0_dp
+    enddo
+    Tb(:,1) = T
+    call system_clock(count_rate=rate)
+    rad%sync_spectra = .false.
+    do mode = 0, 1
+      call rad%set_ir_green(mode)
+      best(mode+1) = huge(1.0_dp)
+      do rep = 1, 4
+        call system_clock(c0)
+        call rad%radiate_ir_batch(Tsb, Tb, bup, bdn, bft, err)
+        call system_clock(c1)
+        call check()
+        if (rep > 1) best(mode+1) = min(best(mode+1), 1.0e3_dp*real(c1 - c0, dp)/real(rate, dp))
+      enddo
+      if (mode == 0) gft = bft
+    enddo
+    call system_clock(c0)
+    do c = 1, nz + 1
+      if (np > 0) then
+        call rad%radiate(Tsb(c), Tb(:,c), P, densities, dz, pdensities, radii, compute_solar=.false., compute_opacity=.false., err=err)
+      else
+        call rad%radiate(Tsb(c), Tb(:,c), P, densities, dz, compute_solar=.false., compute_opacity=.false., err=err)
+      endif
+    enddo
+    call system_clock(c1)
+    call check()
+    t_loop = 1.0e3_dp*real(c1 - c0, dp)/real(rate, dp)
+    write(output_unit,'(a,i0,a,i0,a,f7.2,a,f7.2,a,f8.2,a,es9.2,a,i0)') 'fortran host, RCE Jacobian: ', nz+1, ' IR-only columns x ', nz, &
+      ' layers: rad%radiate_ir_batch ', best(2), ' ms (general kernel ', best(1), ' ms), one rad%radiate at a time ', t_loop, &
+      ' ms; largest difference between the two batch forms ', maxval(abs(bft - gft))/maxval(abs(gft)), &
+      ' of the maximum; batches in the response form: ', rad%ir_green_batches()
+  end subroutine
+
   subroutine time_calls()
     use iso_fortran_env, only: int64
     integer :: ncalls, k, pass

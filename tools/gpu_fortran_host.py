@@ -17,4 +17,12 @@ with tempfile.TemporaryDirectory() as d:
     out = subprocess.run([exe, case, os.path.join(d, "out.txt"), "time", n], capture_output=True, text=True, timeout=600)
     print("nz %d, nw %d, 8 zenith angles:" % (nz, nw))
     print(out.stdout.strip() or out.stderr.strip())
-    sys.exit(out.returncode)
+    if out.returncode:
+        sys.exit(out.returncode)
+    # the RCE Jacobian's batch from the same host (`jac` mode), on this grid and on AdiabatClimate's 402-layer doubled grid
+    for nzj in (nz, 402):
+        write_case(case, S.modern_earth_tables(nw=nw), S.modern_earth_column(nzj), 4, 0.15)
+        out = subprocess.run([exe, case, os.path.join(d, "out.txt"), "jac"], capture_output=True, text=True, timeout=600)
+        print(out.stdout.strip() or out.stderr.strip())
+        if out.returncode:
+            sys.exit(out.returncode)
