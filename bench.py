@@ -402,6 +402,10 @@ def main():
             out["rce_jacobian_batch"] = jac
         if not args.no_cpu_baseline:   # rank 0, every N (the other ranks wait at the final barrier)
             out.update(cpu_baseline(tables, col, nz, nzen, albedo, olr, rad if world == 1 else None, 0.4286 if cfg == 3 else None))
+            if jac is not None:   # the same batch as the reference issues it: nz+1 IR-only calls, here the oracle's on the host cores
+                out["rce_jacobian_batch"]["cpu_port_ms"] = out["cpu_baseline"]["ir_only_call_ms"] * (nz + 1)
+                out["rce_jacobian_batch"]["cpu_port_what"] = ("%d x one IR-only oracle call on the stored opacities (%d threads, %.1f ms each, "
+                                                              "4 timed)" % (nz + 1, out["cpu_baseline"]["cores"], out["cpu_baseline"]["ir_only_call_ms"]))
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist_on:
@@ -480,6 +484,11 @@ def cpu_baseline(tables, col, nz, nzen, albedo, olr_gpu, rad=None, photon_scale=
     n1, el1 = timed(1, 8.0, 8)
     O.lib().orc_set_num_threads(cores)
     _, olr_o = o.TOA_fluxes(*col.args())
+    # the Jacobian's unit of work on the CPU: one IR-only call on the stored opacities (clima_adiabat_solve.f90:811-812)
+    t0 = time.perf_counter()
+    for _ in range(4):
+        o.radiate(*col.args(), compute_solar=False, compute_opacity=False)
+    ir_only_ms = 1e3 * (time.perf_counter() - t0) / 4
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -490,6 +499,7 @@ def cpu_baseline(tables, col, nz, nzen, albedo, olr_gpu, rad=None, photon_scale=
                             "sample": "%d whole radiate() calls of the same workload (%.1f s)" % (n, el),
                             "single_thread": {"value": n1 / el1, "unit": "calls/s",
                                               "sample": "%d calls (%.1f s)" % (n1, el1)},
+                            "ir_only_call_ms": ir_only_ms,
                             "cpu_model": model, "host_cpus": os.cpu_count()},
            "olr_rel_err_vs_cpu": abs(olr_gpu - olr_o) / abs(olr_o)}
     if rad is not None:  # level fluxes of both channels and the planetary albedo
