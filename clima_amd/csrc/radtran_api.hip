@@ -1978,6 +1978,44 @@ void clima_bench_resident_sync(void *ptr, const int *n, double *us, char *err) {
   }
 }
 
+// Bench hook (timing only): ONE resident call's launches captured into a hipGraph, then `n` times hipGraphLaunch +
+// stream synchronise, timed one by one -- what a graph would make of clima_bench_resident_sync's loop.  The replayed
+// launches carry the captured call's id, so the two-stream blocks of the fused grid find their flags already set and
+// do not wait: results are NOT valid (the handle is marked for a fresh call afterwards), the time is a lower bound
+// (the missing wait is worth ~1 us).  With mode = 1 each pass replays `k` launches of the graph
+// before it synchronises (k calls back to back).  us[n].
+void clima_bench_resident_graph(void *ptr, const int *n, const int *k, double *us, char *err) {
+  clear_err(err);
+  GUARD(r, ptr, err);
+  if (r->state != 2 || !r->column_loaded) { set_err(err, "no column has been uploaded"); return; }
+  TRY
+  const int one = 1;
+  radtran_radiate_resident(ptr, &one, &one, err);     // steady state: buffers allocated, fields uploaded
+  if (err && err[0]) return;
+  HIPCHK(hipStreamSynchronize(r->stream));
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  HIPCHK(hipStreamBeginCapture(r->stream, hipStreamCaptureModeThreadLocal));
+  enqueue_radiate(r, true, true);
+  HIPCHK(hipStreamEndCapture(r->stream, &graph));
+  HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  for (int i = 0; i < 10; i++) HIPCHK(hipGraphLaunch(exec, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  for (int i = 0; i < *n; i++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int j = 0; j < std::max(1, *k); j++) HIPCHK(hipGraphLaunch(exec, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  }
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  r->small_valid = false; r->small_in_host = false; r->opr_valid = false;
+  radtran_radiate_resident(ptr, &one, &one, err);     // leave the handle with a valid call
+  if (err && err[0]) return;
+  HIPCHK(hipStreamSynchronize(r->stream));
+  CATCH(err)
+}
+
 void radtran_apply_radiation_enhancement(void *ptr, const double *rad_enhancement) {
   Radtran *r = as_rad(ptr);
   if (!r || r->state != 2) return;

@@ -74,6 +74,7 @@ SIGNATURES = {
     "clima_bench_toa_fluxes": [_vp, _ip, _dp, _ip, _dp, _ip, _dp, _ip, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _ip, _ip,
                                _dp, _dp, _dp, _dp, _err],
     "clima_bench_resident_sync": [_vp, _ip, _dp, _err],
+    "clima_bench_resident_graph": [_vp, _ip, _ip, _dp, _err],
     "clima_test_device_exp": [_ip, _dp, _dp, _err],
     "clima_test_device_exp_table": [_ip, _ip, _dp, _dp, _err],
     "clima_test_device_rcp": [_ip, _dp, _dp, _err],

@@ -235,6 +235,14 @@ class Radtran:
         self._check()
         return us
 
+    def bench_resident_graph(self, n, k=1):
+        """Timing only: one resident call's launches as a hipGraph, `n` passes of `k` graph launches + synchronize (us
+        per pass); the replayed results are not valid."""
+        us = np.zeros(int(n))
+        self._L.clima_bench_resident_graph(self._ptr, _i(n), _i(k), _d(us), self._err)
+        self._check()
+        return us
+
     def apply_radiation_enhancement(self, rad_enhancement):
         self._L.radtran_apply_radiation_enhancement(self._ptr, _f(rad_enhancement))
 

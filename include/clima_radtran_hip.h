@@ -254,6 +254,9 @@ void clima_bench_toa_fluxes(void *ptr, const int *n, const double *T_surface, co
                             const int *dim1_p, const int *dim2_p, const double *pdensities, const int *dim1_r,
                             const int *dim2_r, const double *radii, double *us, double *ISR, double *OLR, char *err);
 void clima_bench_resident_sync(void *ptr, const int *n, double *us, char *err);
+/* Timing only: one resident call's launches captured into a hipGraph and replayed (k launches per synchronise), us[n]
+ * per pass; the replayed results are not valid (the captured call id makes the fused grid's waits trivial). */
+void clima_bench_resident_graph(void *ptr, const int *n, const int *k, double *us, char *err);
 
 /* test hook: y[i] = the kernels' device exp(x[i]) (used where the reference calls exp) */
 void clima_test_device_exp(const int *n, const double *x, double *y, char *err);
