@@ -213,9 +213,12 @@ void radtran_coop_items_get(void *ptr, int *items);
  * the RCE Jacobian (src/adiabat/clima_adiabat_solve.f90:798-812) are one base profile with one or a few temperatures
  * changed each: such a column is F(base) + unit responses x Planck differences, which costs one exp and two FMAs per
  * (level, deviation, bin, g-point) instead of a solve per (column, bin, g-point).  mode 1 (default): taken when at least
- * 48 columns differ from the profile the batch's columns share in at most 8 temperatures and a cost model of the two forms favours it -- tall grids, few changes per column -- (the others, and the base profile
- * itself, go through the general kernel); 0: never; 2: whenever any column qualifies (tests).  CLIMA_HIP_IR_GREEN
- * sets the default.  Same results to rounding (1e-12 of the level fluxes).  `batches` counts the batches that took it. */
+ * 48 columns differ from the profile the batch's columns share in at most 8 temperatures and a cost model of the two
+ * forms favours it -- tall grids, few changes per column -- (the others, and the base profile itself, go through the
+ * general kernel); not on handles whose ir_tau_min was lowered below 1e-7 (the source slope dB / tau of such thin layers
+ * costs the response form digits first: 1e-8 against 5e-10 of a row's maximum in the fuzz sweep); 0: never; 2: whenever
+ * any column qualifies (tests).  CLIMA_HIP_IR_GREEN sets the default.  Same results to rounding (1e-12 of the level
+ * fluxes at the reference's ir_tau_min).  `batches` counts the batches that took it. */
 void radtran_ir_green_set(void *ptr, const int *mode);
 void radtran_ir_green_get(void *ptr, int *mode, int *batches);
 /* A two-stream block of the fused grid waits (bounded) for the opacity blocks of its bin.  If that
