@@ -32,6 +32,7 @@ run ng_sweep.txt python3 tools/gpu_ng_sweep.py || exit 1
 run ir_batch.txt python3 tools/gpu_ir_batch.py 50 100 200 249 || exit 1
 run fortran_host.txt python3 tools/gpu_fortran_host.py || exit 1      # the drop-in call timed by a Fortran host
 run fortran_like.txt python3 tools/gpu_fortran_like.py || exit 1      # ... and what pushing the public fields before every call costs
+run graph_ab.txt python3 tools/gpu_graph_ab.py || exit 1              # a hipGraph replay of the call's launches beside the plain launches
 # ---- per-phase stamps and the block timeline (the -DCLIMA_STAMPS build, when present)
 if [ -f clima_amd/csrc/libclima_radtran_hip_stamps.so ]; then
   run stamps.txt python3 tools/gpu_stamps.py || exit 1
