@@ -216,3 +216,60 @@ def test_a_profile_that_is_not_a_number_stays_with_the_general_kernel(small_tabl
     assert r.ir_green_batches == 1
     assert np.all(np.isnan(a[0][:, 3])) or np.any(np.isnan(a[0][:, 3]))
     assert np.all(np.isfinite(np.delete(a[0], 3, axis=1)))
+
+
+def test_response_form_with_steps_far_below_what_two_solves_can_resolve(O, small_tables):
+    """A Jacobian's finite-difference step can be 1e-8 T and smaller.  The Planck difference of such a step is formed
+    without subtracting two nearly equal Planck values (k_green_db), and the response form never subtracts two solves: its
+    difference quotients must stay on the derivative -- taken here from the oracle's central differences at a comfortable
+    step -- down to where the returned rows themselves (F(T + dT), not the change) stop resolving it."""
+    from clima_amd import synthetic as S
+    from test_gpu_parity import _pair, _compare
+    nz = 40
+    col = S.modern_earth_column(nz)
+    r, o = _pair(O, small_tables, nz, 2, 0.3)
+    _compare(r, o, col)
+    levels = [0, 3, nz // 2, nz]                       # T index (nz = the surface)
+    rel_steps = [1e-6, 1e-9, 1e-12]
+    ncol = 1 + len(levels) * len(rel_steps)
+    T = np.repeat(np.asarray(col["T"], dtype=float)[:, None], ncol, axis=1)
+    Ts = np.full(ncol, float(col["T_surface"]))
+    dT = np.zeros(ncol)
+    c = 1
+    for j in levels:
+        for rs in rel_steps:
+            base = Ts[c] if j == nz else T[j, c]
+            dT[c] = rs * base
+            if j == nz:
+                Ts[c] = base + dT[c]
+                dT[c] = Ts[c] - base                    # the step as the floating-point numbers carry it
+            else:
+                T[j, c] = base + dT[c]
+                dT[c] = T[j, c] - base
+            c += 1
+    r.ir_green = 2
+    fup, fdn, ftot = r.radiate_ir_batch(Ts, T)
+    assert r.ir_green_batches == 1
+    c = 1
+    for j in levels:
+        # central difference of the oracle at a relative step of 1e-5: truncation ~1e-8 (x^2 step^2 / 6, x = h nu / k T
+        # up to ~20), cancellation ~1e-8
+        d = 1e-5 * (float(col["T_surface"]) if j == nz else float(col["T"][j]))
+        rows = []
+        for sgn in (+1.0, -1.0):
+            w = S.Column(col)
+            w["T"] = np.asarray(col["T"], dtype=float).copy()
+            if j == nz:
+                w["T_surface"] = float(col["T_surface"]) + sgn * d
+            else:
+                w["T"][j] += sgn * d
+            o.radiate(*w.args(), compute_solar=False, compute_opacity=False)
+            rows.append(np.array(o.f_total))
+        want = (rows[0] - rows[1]) / (2.0 * d)
+        for rs in rel_steps:
+            have = (ftot[:, c] - ftot[:, 0]) / dT[c]
+            # the one-sided quotient's own truncation (~x^2 / 2 times the relative step) and the resolution of the RESULT:
+            # the batch returns F(T + dT), not the change, so the caller's subtraction keeps ~1e-16 F / dF
+            tol = 2e-6 + 500.0 * rs + 3e-15 / rs
+            assert np.max(np.abs(have - want)) <= tol * np.max(np.abs(want)), (j, rs, np.max(np.abs(have - want)) / np.max(np.abs(want)))
+            c += 1
