@@ -693,6 +693,49 @@ int orc_get_max_threads(void) {
 #endif
 }
 
+/* Census hook (diagnostics for the build's kernel design, not part of the restated algorithm): when a
+ * buffer is set, every random-overlap mixing step records, per (bin l, step jj-1, layer i) in
+ * buf[((l*(nk-1) + jj-1)*nz + i)*4 + 0..3]:
+ *   [0] flags: 1 = y ascending, 2 = x ascending, 4 = max(y)-min(y) <= smallest gap of x (the ng*ng sums are
+ *       already ascending in the order of types.f90:826-830, "row-major"), 8 = max(x)-min(x) <= smallest gap
+ *       of y ("column-major"), 16 / 32 = the same two with the range also allowed up to 2^-46 of the smallest
+ *       sum, 64 = layer copied by pair_reuse (no sort)
+ *   [1] number of neighbouring x gaps smaller than the range of y   [2] the same with x and y exchanged
+ *   [3] number of inversions of the row-major order against the sorted one, saturated at 255 */
+static unsigned char *g_census = NULL;
+void orc_census_set(unsigned char *buf) { g_census = buf; }
+
+static void census_step(unsigned char *o, int ng, const double *x, int xs, const double *y, const double *xy, const int *inds) {
+  int ys_ = 1, xs_ = 1, nx = 0, ny = 0;
+  double ymin = y[0], ymax = y[0], xmin = x[0], xmax = x[0], gx = 1e300, gy = 1e300;
+  for (int g = 1; g < ng; g++) {
+    if (y[g] < y[g - 1]) ys_ = 0;
+    if (x[g * xs] < x[(g - 1) * xs]) xs_ = 0;
+    ymin = fmin(ymin, y[g]); ymax = fmax(ymax, y[g]);
+    xmin = fmin(xmin, x[g * xs]); xmax = fmax(xmax, x[g * xs]);
+    gx = fmin(gx, x[g * xs] - x[(g - 1) * xs]);
+    gy = fmin(gy, y[g] - y[g - 1]);
+  }
+  for (int g = 1; g < ng; g++) {
+    if (x[g * xs] - x[(g - 1) * xs] < ymax - ymin) nx++;
+    if (y[g] - y[g - 1] < xmax - xmin) ny++;
+  }
+  const double tiny = ldexp(xmin + ymin, -46);
+  int f = ys_ | (xs_ << 1);
+  if (ys_ && xs_) {
+    if (ymax - ymin <= gx) f |= 4;
+    if (xmax - xmin <= gy) f |= 8;
+    if (ymax - ymin <= fmax(gx, tiny)) f |= 16;
+    if (xmax - xmin <= fmax(gy, tiny)) f |= 32;
+  }
+  int inv = 0;
+  for (int a = 0; a < ng * ng && inv < 255; a++)
+    for (int b = a + 1; b < ng * ng; b++)
+      if (inds[a] > inds[b]) { inv++; if (inv >= 255) break; }
+  (void)xy;
+  o[0] = (unsigned char)f; o[1] = (unsigned char)nx; o[2] = (unsigned char)ny; o[3] = (unsigned char)inv;
+}
+
 /* ------------------------------------------------------------------ opacity */
 
 /* interpolate_Xsection, clima_radtran_types.f90:890-917 (res indexed by layer) */
@@ -908,9 +951,15 @@ static int compute_opacity(OrcRadtran *r, const double *P, const double *T,
         for (int i = 0; i < nz; i++) {
           if (pair_reuse[i]) {
             for (int j = 0; j < ng; j++) tau_k[i + (size_t)j * nz] = tau_k[i - 1 + (size_t)j * nz];
+            if (g_census) g_census[(((size_t)l * (r->nk - 1) + jj - 1) * nz + i) * 4] = 64;
           } else {
             for (int j = 0; j < nxy; j++) tau_xy1[j] = tau_xy[i + (size_t)j * nz];
             orc_mrgrnk(nxy, tau_xy1, inds);
+            if (g_census) {
+              double yv[64] = {0};
+              for (int j = 0; j < ng && j < 64; j++) yv[j] = ks[((size_t)jj * ng + j) * nz + i] * cols[i + (size_t)j2 * nz];
+              census_step(g_census + (((size_t)l * (r->nk - 1) + jj - 1) * nz + i) * 4, ng, tau_k + i, nz, yv, tau_xy1, inds);
+            }
             for (int j = 0; j < nxy; j++) {
               tau_xy2[j] = tau_xy1[inds[j]];
               wxy1[j] = r->wxy[inds[j]];

@@ -70,6 +70,7 @@ void orc_set_surface_emissivity(OrcRadtran *r, const double *e /* nw_ir */);
 void orc_set_scalars(OrcRadtran *r, double diurnal_fac, int has_hard_surface,
                      double ir_tau_min, double photon_scale_factor);
 void orc_set_num_threads(int n);
+void orc_census_set(unsigned char *buf); /* diagnostics: per mixing step order statistics, see clima_oracle.c */
 int orc_get_max_threads(void);
 
 /* ---- the path ---- */
