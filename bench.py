@@ -80,8 +80,56 @@ def pmc_for(kernel, workload_key):
     return k, rec.get("source")
 
 
+def visible_gpus():
+    """Number of devices this process could open, WITHOUT initialising the GPU (on this image
+    torch.cuda.device_count() reads the topology only)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launcher_command(n, argv, port=None):
+    """The command that starts the N ranks: the driver's own form of the N > 1 launch."""
+    if port is None:
+        port = 29500 + (os.getpid() % 400)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv, run=None, ndev=None):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N ranks as fresh
+    child processes -- this process has not touched the GPU and never will -- pass rank 0's JSON line through,
+    exit with the children's code.  Before the run proper the library's own RCCL step (communicator created by
+    radtran_comm_init_rank, ncclAllReduce on the handle's stream) is tried on the same N ranks in a short child job
+    under a time limit: it has not run on more than one GPU yet, so the measured run takes it only when
+    that job came back clean and otherwise keeps torch.distributed's all-reduce."""
+    import subprocess
+    run = run or subprocess.run
+    ndev = visible_gpus() if ndev is None else ndev
+    if ndev < n:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (n, ndev))
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    if "CLIMA_BENCH_NATIVE_ALLREDUCE" not in env and "CLIMA_BENCH_TORCH_ALLREDUCE" not in env:
+        probe_env = dict(env, CLIMA_BENCH_NATIVE_ALLREDUCE="1")
+        try:
+            pr = run(launcher_command(n, ["--gpus", str(n), "--probe-native"]), env=probe_env, timeout=240,
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            ok = pr.returncode == 0 and b"native step ok" in (pr.stdout or b"")
+        except subprocess.TimeoutExpired:
+            ok = False
+        sys.stderr.write("bench.py: library-owned RCCL step on %d ranks: %s\n" % (n, "ok, used" if ok else "NOT clean, torch's all-reduce used"))
+        env["CLIMA_BENCH_NATIVE_ALLREDUCE"] = "1" if ok else "0"
+    r = run(launcher_command(n, argv), env=env)
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--probe-native", action="store_true",
+                    help="(launcher's use) three steps through the library's own RCCL step on the N ranks, checked against "
+                         "the same steps with torch's all-reduce; prints 'native step ok'")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=200)
@@ -93,6 +141,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-jacobian", action="store_true", help="skip the RCE-Jacobian batch figure (rce_jacobian_batch)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly one JSON line: anything libraries print there (RCCL's version
     # banner at communicator creation, for one) is routed to stderr
@@ -108,8 +159,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d inside a job of %d rank(s)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Radtran hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -146,7 +196,20 @@ def main():
     if cfg == 4:
         return config4(args, rad, tables, nz, nzen, world, rank, dist_on, dist, torch, json_fd)
 
-    torch_ar = os.environ.get("CLIMA_BENCH_TORCH_ALLREDUCE") == "1"
+    # Which all-reduce ends a sharded step.  The library's own (radtran_comm_init_rank: ncclAllReduce on the handle's
+    # stream) is what a Fortran / C host gets and what the one-rank rehearsals and tests run; it has not yet run
+    # across two GPUs (no box of this pool offers two), so for world > 1 it is taken only when asked for:
+    # CLIMA_BENCH_NATIVE_ALLREDUCE=1 -- which `python bench.py --gpus N` sets by itself after trying that step on the
+    # N ranks in a short child job (self_launch) -- and torch.distributed's all-reduce on a tensor aliasing the
+    # library's buffer otherwise.  CLIMA_BENCH_TORCH_ALLREDUCE=1 forces the latter also for the rehearsal.
+    if os.environ.get("CLIMA_BENCH_TORCH_ALLREDUCE") == "1":
+        torch_ar = True
+    elif world > 1:
+        torch_ar = os.environ.get("CLIMA_BENCH_NATIVE_ALLREDUCE") != "1"
+    else:
+        torch_ar = False
+    if args.probe_native:
+        return probe_native(rad, col, nz, world, rank, dist, torch, json_fd)
     if dist_on:
         if torch_ar:
             rad.set_bin_shard(rank, world)
@@ -414,6 +477,68 @@ def main():
         dist.destroy_process_group()
 
 
+def probe_native(rad, col, nz, world, rank, dist, torch, json_fd):
+    """The library-owned RCCL step on the job's ranks, checked against torch's all-reduce of the same partial rows:
+    a full step, an IR-only step on the stored opacities (the partial solar rows are put back before the reduce),
+    and a forced hand-off timeout on rank 0 (radtran_fused_spins_set(0): the status word makes every rank repeat the
+    step).  Rank 0 prints `native step ok` when every row agrees to 1e-13 of its maximum on every rank."""
+    import numpy as np
+    from clima_amd.radtran import Radtran
+
+    def rows(r):
+        return np.concatenate([np.asarray(r.wrk_ir.fup_n), np.asarray(r.wrk_ir.fdn_n), np.asarray(r.wrk_sol.fup_n),
+                               np.asarray(r.wrk_sol.fdn_n), np.asarray(r.f_total)])
+
+    # reference: shard + torch all-reduce (host-synchronised: the plainest form)
+    rad.set_bin_shard(rank, world)
+    rad.upload_column(*col.args())
+    flux = rad.flux_tensor()
+    want = []
+    for solar in (True, False):
+        rad.radiate_resident(compute_solar=solar)
+        rad.synchronize()
+        if not solar:   # the reduced solar rows of the step before are overwritten by this rank's share again
+            pass
+        dist.all_reduce(flux)
+        torch.cuda.synchronize()
+        rad.finish_reduced()
+        want.append(rows(rad))
+    rad.set_bin_shard(0, 1)
+    # the library's own step on a fresh handle state
+    ids = [Radtran.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    rad.comm_init_rank(world, rank, ids[0])
+    rad.upload_column(*col.args())
+    got = []
+    for solar in (True, False):
+        rad.radiate_resident(compute_solar=solar)
+        rad.synchronize()
+        got.append(rows(rad))
+    n0 = rad.fused_fallbacks
+    spins = rad.fused_spins
+    if rank == 0:
+        rad.fused_spins = 0
+    rad.radiate_resident()
+    rad.synchronize()
+    rad.fused_spins = spins
+    got.append(rows(rad))
+    want.append(want[0])
+    err = max(float(np.max(np.abs(g - w)) / np.max(np.abs(w))) for g, w in zip(got, want))
+    t = torch.tensor([err], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    err = float(t[0])
+    rad.synchronize()
+    dist.barrier()
+    rad.comm_destroy()
+    dist.destroy_process_group()
+    if rank == 0:
+        msg = "native step %s: largest difference from torch's all-reduce %.2e of a row's maximum on %d ranks, repeated steps %d\n" % (
+            "ok" if err < 1e-13 else "DIFFERS", err, world, rad.fused_fallbacks - n0)
+        os.write(json_fd, msg.encode())
+    if err >= 1e-13:
+        sys.exit(3)
+
+
 def config4(args, rad, tables, nz, nzen, world, rank, dist_on, dist, torch, json_fd):
     """BASELINE.json config 4: `--ncol` perturbed ModernEarth columns (seed 7) through
     radtran_toa_fluxes_batch; a step = the whole batch; with N ranks every rank takes ncol/N columns,
@@ -457,14 +582,57 @@ def config4(args, rad, tables, nz, nzen, world, rank, dist_on, dist, torch, json
         dist.destroy_process_group()
 
 
+def physical_cores():
+    """(physical cores this process may use, how that was determined).  The CPUs of the affinity mask, counted
+    once per (package, core) pair of /sys/devices/system/cpu/cpuN/topology -- SMT siblings share a pair -- and
+    capped by the cgroup's CPU quota when there is one."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    seen, how = set(), "topology"
+    for c in cpus:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            with open(base + "physical_package_id") as f:
+                pkg = f.read().strip()
+            with open(base + "core_id") as f:
+                core = f.read().strip()
+            seen.add((pkg, core))
+        except OSError:
+            seen, how = set(), "no topology files"
+            break
+    n = len(seen) if seen else len(cpus)
+    what = "%d CPUs in the affinity mask, %s" % (len(cpus), "%d distinct (package, core) pairs" % n if seen else how)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith("cpu.max"):
+                quota = None if fields[0] == "max" else float(fields[0]) / float(fields[1])
+            else:
+                q = float(fields[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    quota = None if q <= 0 else q / float(g.read().split()[0])
+            if quota is not None and quota < n:
+                n = max(1, int(quota))
+                what += ", cgroup quota %.1f CPUs" % quota
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n), what
+
+
 def cpu_baseline(tables, col, nz, nzen, albedo, olr_gpu, rad=None, photon_scale=None):
     """The oracle (port of the reference algorithm, OpenMP over bins like the reference's
-    `!$omp parallel do`) on this box's host cores: whole radiate() calls of the same
-    workload, bounded to ~10-30 s in all.  Timed at all usable cores (the figure in `value`)
-    and at one thread (the reference's Python default, clima/__init__.py:2)."""
+    `!$omp parallel do`, /root/reference/src/radtran/clima_radtran_types.f90:638-640 and
+    clima_radtran_radiate.f90:50-52) on this box's host cores: whole radiate() calls of the same workload,
+    bounded to ~25 s in all.  SURVEY 8(d): timed at ONE thread (the reference's Python default,
+    clima/__init__.py:2) and at ALL PHYSICAL cores (`value`, `cores`); 16 threads are timed as well (the figure
+    of rounds 1-3, and the share of a 1-GPU box that its worker pools are sized for)."""
     from oracle import oracle as O
     O.build()
-    cores = min(os.cpu_count() or 1, 16)
+    cores, cores_how = physical_cores()
     o = O.OracleRadtran(tables, nz, nzen, albedo)
     if photon_scale is not None:
         o.set_scalars(photon_scale_factor=photon_scale)
@@ -480,8 +648,11 @@ def cpu_baseline(tables, col, nz, nzen, albedo, olr_gpu, rad=None, photon_scale=
             if el > budget or n >= cap:
                 return n, el
 
-    n, el = timed(cores, 10.0, 40)
-    n1, el1 = timed(1, 8.0, 8)
+    n, el = timed(cores, 8.0, 200)
+    n16 = el16 = None
+    if cores != 16 and cores > 16:
+        n16, el16 = timed(16, 5.0, 40)
+    n1, el1 = timed(1, 6.0, 6)
     O.lib().orc_set_num_threads(cores)
     _, olr_o = o.TOA_fluxes(*col.args())
     # the Jacobian's unit of work on the CPU: one IR-only call on the stored opacities (clima_adiabat_solve.f90:811-812)
@@ -497,8 +668,11 @@ def cpu_baseline(tables, col, nz, nzen, albedo, olr_gpu, rad=None, photon_scale=
         pass
     out = {"cpu_baseline": {"value": n / el, "unit": "calls/s", "cores": cores, "kind": "port",
                             "sample": "%d whole radiate() calls of the same workload (%.1f s)" % (n, el),
+                            "cores_how": cores_how,
                             "single_thread": {"value": n1 / el1, "unit": "calls/s",
                                               "sample": "%d calls (%.1f s)" % (n1, el1)},
+                            "threads_16": ({"value": n16 / el16, "unit": "calls/s", "sample": "%d calls (%.1f s)" % (n16, el16)}
+                                           if n16 else None),
                             "ir_only_call_ms": ir_only_ms,
                             "cpu_model": model, "host_cpus": os.cpu_count()},
            "olr_rel_err_vs_cpu": abs(olr_gpu - olr_o) / abs(olr_o)}

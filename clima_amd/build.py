@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libclima_radtran_hip.so")
 SOURCES = ["kernels.hip", "radtran_api.hip"]
-DEPS = SOURCES + ["radtran_dev.h", "sort_network_64.inc", "ir_green.inc", os.path.join("..", "..", "include", "clima_radtran_hip.h")]
+DEPS = SOURCES + ["radtran_dev.h", "sort_network_64.inc", "rorr_xys_asm.inc", "ir_green.inc", os.path.join("..", "..", "include", "clima_radtran_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # The kernels take their parameter blocks by value; hipcc reads them straight from the kernel-argument
 # segment (scalar loads) only while a block has at most `instcombine-max-copied-from-constant-users` uses

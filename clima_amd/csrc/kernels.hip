@@ -622,12 +622,21 @@ __device__ __forceinline__ void rebin_window(const double (&key)[64], const bool
   for (int q = 1; q < 8; q++) out[q] = (Ie[q + 1] - Ie[q]) * rW[q];
 }
 
+#include "rorr_xys_asm.inc"
+#ifdef CLIMA_STAMPS
+#include "rorr_xys_asm_dbg.inc"
+#endif
+#ifndef CLIMA_RORR_ASM
+#define CLIMA_RORR_ASM 1
+#endif
+constexpr bool RORR_ASM = CLIMA_RORR_ASM != 0;   // (0: the compiler-scheduled step of rounds 1-3, for A/B timing)
+
 template <int RM>
 __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y)[8],
                                           double (*sI)[OP_THREADS], const int tid, const int tile,
                                           const double *s_wxy, const double *s_E,
                                           const double *s_Ew, const double *rW,
-                                          double (&out)[8], long long *stamps = nullptr, const int stamp_slot = 0) {
+                                          double (&out)[8], const double *rorr_tab, long long *stamps = nullptr, const int stamp_slot = 0) {
   (void)stamps; (void)stamp_slot;   // diagnostic build only: where the "sort done" stamp of this mixing step goes
   double key[64];
   bool ysorted = true, xsorted = true;
@@ -635,6 +644,46 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
   for (int j = 0; j < 7; j++) {
     ysorted = ysorted && (y[j] <= y[j + 1]);
     xsorted = xsorted && (x[j] <= x[j + 1]);
+  }
+  const bool ys = __all(ysorted), xys = ys && __all(xsorted);
+  if constexpr (RM == 0 && RORR_ASM) {
+    // x and y ascending (the normal case: k-coefficients ascend in g, and so does a rebinned mixture) with the
+    // window-form rebin: the whole step is one block of generated assembly (rorr_xys_asm.inc,
+    // tools/gen_rorr_asm.py) that leaves out the merges and the rebin rows the wave's operands make unnecessary.
+    if (xys) {
+      double xx[8], yy[8];
+#pragma unroll
+      for (int g = 0; g < 8; g++) { xx[g] = x[g]; yy[g] = y[g]; }
+      typedef __attribute__((address_space(3))) const double lds_cdouble;
+      const unsigned wxy_addr = (unsigned)(unsigned long)(lds_cdouble *)s_wxy;   // 512-byte aligned (opacity8_body)
+#ifdef CLIMA_STAMPS
+      // diagnostic build: the block's own s_memtime samples (start, keys built, sorted, rebinned, end), the rows it
+      // rebinned and its merge mask, for the first wave of every 50th tile
+      int d0, d1, d2, d3, d4, drows, dskip;
+      asm volatile(RORR_XYS_ASM_DBG_TEXT
+                   : "+v"(xx[0]), "+v"(xx[1]), "+v"(xx[2]), "+v"(xx[3]), "+v"(xx[4]), "+v"(xx[5]), "+v"(xx[6]), "+v"(xx[7]),
+                     "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(yy[4]), "+v"(yy[5]), "+v"(yy[6]), "+v"(yy[7])
+                   : "v"(wxy_addr), "s"(rorr_tab)
+                   : RORR_XYS_ASM_DBG_CLOBBERS);
+      asm volatile("s_mov_b32 %0, s98\n\ts_mov_b32 %1, s100\n\ts_mov_b32 %2, s40\n\ts_mov_b32 %3, s44\n\ts_mov_b32 %4, s46\n\t"
+                   "s_mov_b32 %5, s43\n\ts_mov_b32 %6, s42"
+                   : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(drows), "=s"(dskip));
+      if (stamps && tile % 50 == 0 && threadIdx.x == 0) {
+        long long *q = stamps + 7000 + ((tile / 50) * 4 + (stamp_slot - 22)) * 8;
+        q[0] = d0; q[1] = d1; q[2] = d2; q[3] = d3; q[4] = d4; q[5] = drows; q[6] = dskip; q[7] = 1;
+      }
+#else
+      asm volatile(RORR_XYS_ASM_TEXT
+                   : "+v"(xx[0]), "+v"(xx[1]), "+v"(xx[2]), "+v"(xx[3]), "+v"(xx[4]), "+v"(xx[5]), "+v"(xx[6]), "+v"(xx[7]),
+                     "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(yy[4]), "+v"(yy[5]), "+v"(yy[6]), "+v"(yy[7])
+                   : "v"(wxy_addr), "s"(rorr_tab)
+                   : RORR_XYS_ASM_CLOBBERS);
+#endif
+#pragma unroll
+      for (int g = 0; g < 8; g++) out[g] = yy[g];   // the new coefficients come back in the y operands
+      STAMP(stamps, stamp_slot);
+      return;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -656,7 +705,8 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
 // exchanges that operands ascending in both x and y never need (sort_network_64.inc)
 #define CE_X(a, b) \
   if (!xys) CE(a, b)
-  const bool ys = __all(ysorted), xys = ys && __all(xsorted);
+#define CE_MERGE_BEGIN(P, M)
+#define CE_MERGE_END
   if (!ys) {
 #define CE_FULL_HEAD
 #include "sort_network_64.inc"
@@ -687,6 +737,8 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
 #define CE_L32_REST
 #include "sort_network_64.inc"
 #undef CE_L32_REST
+#undef CE_MERGE_BEGIN
+#undef CE_MERGE_END
 #undef CE_X
 #undef CE
   STAMP(stamps, stamp_slot);
@@ -778,7 +830,7 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   const ColumnDev &c = p.col;
   constexpr int NG = 8;
   __shared__ double sI[RM == 0 ? 1 : NG][OP_THREADS];  // streaming rebin: per-lane private slots (slot-major: conflict-free)
-  __shared__ double s_wxy[NG * NG];
+  __shared__ __align__(512) double s_wxy[NG * NG];   // (512: the assembly forms a weight's address as base | key bits 3-8)
   __shared__ double s_E[NG + 4];  // output edges followed by +inf sentinels
   const int tid = threadIdx.x;
   // wave-uniform tables read where they are used: the g-point edges E_0..E_8, then the g-point weights
@@ -905,7 +957,17 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   };
   LayerTerms lt;
   const bool terms_first = (__builtin_amdgcn_s_getreg(HWREG_HW_ID_WAVE_ID) & 1) == 0;
-  if (terms_first) layer_terms(j, lt);
+  // A wave that takes them first parks them in LDS for the mixing loop: the assembly block of a mixing step
+  // (rorr_xys_asm.inc) names 192 registers, and every value the compiler has to carry across it beyond the 64 that
+  // are left is spilled and reloaded through L2 with the wave stalled.
+  __shared__ double s_lt[7][OP_THREADS];
+  if (terms_first) {
+    layer_terms(j, lt);
+    if constexpr (RM == 0 && RORR_ASM) {
+      s_lt[0][tid] = lt.tausg; s_lt[1][tid] = lt.taua; s_lt[2][tid] = lt.tauc; s_lt[3][tid] = lt.tausc;
+      s_lt[4][tid] = lt.taup; s_lt[5][tid] = lt.tausp; s_lt[6][tid] = lt.gt;
+    }
+  }
 
   STAMP(p.stamps, 1);
   // ---- k-distributions (:649-662) and random-overlap mixing (k_rorr :816-854)
@@ -937,13 +999,18 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   for (int s = 0; s < p.nk; s++) {
     const int iP = iP_n, iT = iT_n;
     const double q1 = q1_n, q2 = q2_n;
+    // the layer index as the loop body sees it: opaque, so that the addresses formed from it are formed here and not
+    // once before the loop -- hoisted, they are 64-bit values that have to live across the mixing step's assembly
+    // block (192 named registers), and the ones that do not fit are spilled and reloaded every iteration
+    int jv = j;
+    if constexpr (RM == 0 && RORR_ASM) asm volatile("" : "+v"(jv));
     if (s + 1 < p.nk) {
       const KDev &kn = p.k[s + 1];
-      iP_n = c.ix[2 * opf + kn.slotP * nz + j]; iT_n = c.ix[2 * opf + kn.slotT * nz + j];
-      q1_n = c.q[opf + kn.slotP * nz + j]; q2_n = c.q[opf + kn.slotT * nz + j];
+      iP_n = c.ix[2 * opf + kn.slotP * nz + jv]; iT_n = c.ix[2 * opf + kn.slotT * nz + jv];
+      q1_n = c.q[opf + kn.slotP * nz + jv]; q2_n = c.q[opf + kn.slotT * nz + jv];
     }
     double kc[NG];
-    k_times_col(s, j, iP, iT, q1, q2, kc);
+    k_times_col(s, jv, iP, iT, q1, q2, kc);
     STAMP(p.stamps, 2 + 3 * s);
     if (s == 0) {
 #pragma unroll
@@ -953,13 +1020,18 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
       if (tile == 100 && threadIdx.x == 0) g_stamp_buf = p.stamps;
 #endif
       double out[NG];
-      rorr_mix8<RM>(tk, kc, sI, tid, tile, s_wxy, s_E, s_Ew, rW, out, p.stamps, 21 + s);   // (slots 22..25: 32.. belong to the two-stream blocks)
+      rorr_mix8<RM>(tk, kc, sI, tid, tile, s_wxy, s_E, s_Ew, rW, out, p.rorr_tab, p.stamps, 21 + s);   // (slots 22..25: 32.. belong to the two-stream blocks)
 #pragma unroll
       for (int g = 0; g < NG; g++) tk[g] = out[g];
       STAMP(p.stamps, 4 + 3 * s);
     }
   }
-  if (!terms_first) layer_terms(j, lt);
+  if (!terms_first) {
+    layer_terms(j, lt);
+  } else if constexpr (RM == 0 && RORR_ASM) {
+    lt.tausg = s_lt[0][tid]; lt.taua = s_lt[1][tid]; lt.tauc = s_lt[2][tid]; lt.tausc = s_lt[3][tid];
+    lt.taup = s_lt[4][tid]; lt.tausp = s_lt[5][tid]; lt.gt = s_lt[6][tid];
+  }
   STAMP(p.stamps, 20);
 #ifdef CLIMA_STAMPS
   if (p.stamps && (tid & 63) == 0) {

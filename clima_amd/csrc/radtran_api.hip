@@ -130,7 +130,7 @@ struct Radtran {
   std::vector<double> cont_temp, cont_H2O, cont_foreign;
   DevBuf<double> d_cont_temp, d_cont_H2O, d_cont_foreign;
   std::vector<double> wbin, wbin_e, wxy;
-  DevBuf<double> d_wbin, d_wbin_e, d_wbin_e_pad, d_wxy, d_freq;
+  DevBuf<double> d_wbin, d_wbin_e, d_wbin_e_pad, d_wxy, d_freq, d_rorr_tab;
   ChannelObj ir, sol;
   WrkObj wrk_ir, wrk_sol;
   // public fields (clima_radtran.f90:51-68)
@@ -705,7 +705,7 @@ void enqueue_radiate(Radtran *r, bool compute_solar, bool compute_opacity, bool 
     for (int e = 0; e < op.nabs; e++) op.abs[e] = r->abs_entries[e];
     for (size_t i = 0; i < r->part.size(); i++)
       op.part[i] = PartDev{r->part[i]->d_w0.p, r->part[i]->d_qext.p, r->part[i]->d_gt.p, r->part[i]->p_ind, r->part[i]->nrad, r->part_slot[i]};
-    op.wbin = r->d_wbin.p; op.wbin_e = r->d_wbin_e.p; op.wxy = r->d_wxy.p; op.wbin_e_pad = r->d_wbin_e_pad.p;
+    op.wbin = r->d_wbin.p; op.wbin_e = r->d_wbin_e.p; op.wxy = r->d_wxy.p; op.wbin_e_pad = r->d_wbin_e_pad.p; op.rorr_tab = r->d_rorr_tab.p;
     op.col = col;
     op.cust = CustomDev{r->d_cust_dtau.p, r->d_cust_w0.p, r->d_cust_g0.p, r->cust_nP, r->nslots, r->cust_on ? 1 : 0};
     op.rebin_mode = r->rebin_mode;
@@ -1269,6 +1269,14 @@ void radtran_coop_items_get(void *ptr, int *items) {
   Radtran *r = as_rad(ptr);
   *items = r ? (int)std::min<long>(r->coop_items, 2147483647L) : 0;
 }
+void radtran_fused_spins_set(void *ptr, const int *spins) {
+  Radtran *r = as_rad(ptr);
+  if (r) r->fused_max_spins = std::max(0, *spins);
+}
+void radtran_fused_spins_get(void *ptr, int *spins) {
+  Radtran *r = as_rad(ptr);
+  *spins = r ? r->fused_max_spins : 0;
+}
 void radtran_ir_green_set(void *ptr, const int *mode) {
   Radtran *r = as_rad(ptr);
   if (r) r->ir_green_mode = std::max(0, std::min(2, *mode));
@@ -1380,6 +1388,16 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
     std::vector<double> pad = r->wbin_e;
     for (int i = 0; i < 4; i++) pad.push_back(INFINITY);
     r->d_wbin_e_pad.upload(pad);
+    // the tables the assembly form of the mixing step keeps in scalar registers (8 g-points): E_1..E_8, w, 1/width --
+    // the reciprocal formed as the opacity tile forms it (1.0 / (E_(k+1) - E_k))
+    std::vector<double> tab(24, 0.0);
+    if (r->ng == 8)
+      for (int k = 0; k < 8; k++) {
+        tab[k] = r->wbin_e[k + 1];
+        tab[8 + k] = r->wbin[k];
+        tab[16 + k] = 1.0 / (r->wbin_e[k + 1] - r->wbin_e[k]);
+      }
+    r->d_rorr_tab.upload(tab);
   }
   r->d_freq.upload(r->freq);
   r->ir.d_freq.upload(r->ir.freq); r->sol.d_freq.upload(r->sol.freq);

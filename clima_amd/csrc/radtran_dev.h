@@ -137,6 +137,7 @@ struct OpacityParams {
   PartDev part[MAX_PART];
   const double *wbin, *wbin_e, *wxy;      // Ksettings (types.f90:84-94)
   const double *wbin_e_pad;               // wbin_e followed by +inf sentinels (edge stream of the rebin)
+  const double *rorr_tab;                 // ng = 8: [E_1..E_8, w_0..w_7, 1/(E_(k+1)-E_k)], read into scalar registers by rorr_xys_asm.inc
   ColumnDev col;
   double *tau, *w0, *g, *tau_band;        // opr
   double *scat;                           // [nw][nz] scattering optical depth tausg + tausp + tausc of a layer (every g-point's

@@ -416,6 +416,18 @@ class Radtran:
         self._L.radtran_coop_items_set(self._ptr, _i(int(n)))
 
     @property
+    def fused_spins(self):
+        """Polls a two-stream block of the fused grid spends waiting for its opacity tiles (0: every wait expires and
+        the call is repeated through separate launches)."""
+        v = C.c_int()
+        self._L.radtran_fused_spins_get(self._ptr, C.byref(v))
+        return v.value
+
+    @fused_spins.setter
+    def fused_spins(self, n):
+        self._L.radtran_fused_spins_set(self._ptr, _i(int(n)))
+
+    @property
     def ir_green(self):
         """radiate_ir_batch's response form: 0 never, 1 (default) when enough columns are sparse deviations of one
         profile, 2 whenever any is."""

@@ -208,6 +208,11 @@ void radtran_fused_get(void *ptr, int *enabled);
  * (CLIMA_HIP_COOP_ITEMS); 0 turns the group-of-lanes form off.  Same results to rounding (6e-14). */
 void radtran_coop_items_set(void *ptr, const int *items);
 void radtran_coop_items_get(void *ptr, int *items);
+/* How many polls a two-stream block of the fused grid spends on its opacity tiles' flags before it gives up and the call
+ * is repeated through separate launches (radtran_fused_fallbacks_get counts those).  Default 400000 (~0.2 s;
+ * CLIMA_HIP_FUSED_SPINS); 0 makes every wait expire -- how the tests and bench.py's multi-GPU probe force the repeat. */
+void radtran_fused_spins_set(void *ptr, const int *spins);
+void radtran_fused_spins_get(void *ptr, int *spins);
 /* radtran_radiate_ir_batch, response form.  With the opacities fixed two_stream_ir
  * (src/radtran/clima_radtran_twostream.f90:156-295) is linear in the Planck values of the levels, and the columns of
  * the RCE Jacobian (src/adiabat/clima_adiabat_solve.f90:798-812) are one base profile with one or a few temperatures

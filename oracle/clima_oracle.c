@@ -700,7 +700,8 @@ int orc_get_max_threads(void) {
  *       already ascending in the order of types.f90:826-830, "row-major"), 8 = max(x)-min(x) <= smallest gap
  *       of y ("column-major"), 16 / 32 = the same two with the range also allowed up to 2^-46 of the smallest
  *       sum, 64 = layer copied by pair_reuse (no sort)
- *   [1] number of neighbouring x gaps smaller than the range of y   [2] the same with x and y exchanged
+ *   [1] bit g-1 set: x(g) - x(g-1) >= range of y (rows g-1 and g of the sums do not interleave)   [2] the same
+ *       with x and y exchanged
  *   [3] number of inversions of the row-major order against the sorted one, saturated at 255 */
 static unsigned char *g_census = NULL;
 void orc_census_set(unsigned char *buf) { g_census = buf; }
@@ -717,8 +718,8 @@ static void census_step(unsigned char *o, int ng, const double *x, int xs, const
     gy = fmin(gy, y[g] - y[g - 1]);
   }
   for (int g = 1; g < ng; g++) {
-    if (x[g * xs] - x[(g - 1) * xs] < ymax - ymin) nx++;
-    if (y[g] - y[g - 1] < xmax - xmin) ny++;
+    if (g <= 8 && x[g * xs] - x[(g - 1) * xs] >= ymax - ymin) nx |= 1 << (g - 1);
+    if (g <= 8 && y[g] - y[g - 1] >= xmax - xmin) ny |= 1 << (g - 1);
   }
   const double tiny = ldexp(xmin + ymin, -46);
   int f = ys_ | (xs_ << 1);

@@ -49,15 +49,23 @@ def assembly():
 # outside the sort network are the price, and are bounded here.
 BOUNDED = re.compile(r"k_opacity_coopILi(16|32)E")
 BOUND = 64
+# Round 4: the kernels that hold the assembly form of the mixing step (rorr_xys_asm.inc names 192 registers; the
+# compiler keeps what lives across it in the other 64).  What is left is a handful of loop-invariant values spilled
+# once before the species loop and reloaded after it -- none on the path of a mixing step (measured: 84.1 -> 81.8 us
+# per config-2 call against the build without the block, 84.5 with 20 of them still inside the loop).
+ASM_STEP = re.compile(r"k_fusedILi0E|k_opacity8ILi0E")
+ASM_STEP_BOUND = 16
 
 
 def test_hot_kernels_have_no_scratch_traffic(assembly):
     hot = {k: v for k, v in assembly.items() if HOT.search(k)}
     assert len(hot) >= 30, sorted(hot)             # every instantiation of the fused grid and the stand-alone kernels
-    bad = {k: v for k, v in hot.items() if v and not BOUNDED.search(k)}
+    bad = {k: v for k, v in hot.items() if v and not BOUNDED.search(k) and not ASM_STEP.search(k)}
     assert not bad, "scratch instructions in: %s (python tools/scratch_report.py)" % bad
     over = {k: v for k, v in hot.items() if BOUNDED.search(k) and v > BOUND}
     assert not over, "more than %d scratch instructions in: %s" % (BOUND, over)
+    over = {k: v for k, v in hot.items() if ASM_STEP.search(k) and v > ASM_STEP_BOUND}
+    assert not over, "more than %d scratch instructions in: %s" % (ASM_STEP_BOUND, over)
 
 
 def test_build_flags_keep_parameter_blocks_in_the_kernarg_segment():
