@@ -329,6 +329,18 @@ module clima_radtran_hip
       integer(c_int), intent(in) :: dim1, dim2
       real(c_double), intent(out) :: arr(*)
     end subroutine
+    subroutine c_radtran_spectra_get_all(ptr, do_solar, nlev, nw_ir, nw_sol, ir_fup_a, ir_fdn_a, ir_tau_band, &
+                                         sol_fup_a, sol_fdn_a, sol_amean, sol_tau_band, err) bind(c, name="radtran_spectra_get_all")
+      import; type(c_ptr), value :: ptr
+      logical(c_bool), intent(in) :: do_solar
+      integer(c_int), intent(in) :: nlev, nw_ir, nw_sol
+      real(c_double), intent(out) :: ir_fup_a(*), ir_fdn_a(*), ir_tau_band(*)
+      real(c_double), intent(out) :: sol_fup_a(*), sol_fdn_a(*), sol_amean(*), sol_tau_band(*)
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_spectra_release(ptr) bind(c, name="radtran_spectra_release")
+      import; type(c_ptr), value :: ptr
+    end subroutine
     subroutine c_climaradtranwrk_fup_n_get(ptr, dim1, arr) bind(c, name="climaradtranwrk_fup_n_get")
       import; type(c_ptr), value :: ptr
       integer(c_int), intent(in) :: dim1
@@ -546,25 +558,24 @@ contains
     logical, intent(in) :: do_solar
     type(c_ptr) :: p
     integer :: nz
+    logical(c_bool) :: ds
+    character(c_char) :: err_c(err_len+1)
     nz = self%nz
     call c_radtran_wrk_ir_get(self%handle, p)
     call c_climaradtranwrk_fup_n_get(p, nz+1, self%wrk_ir%fup_n)
     call c_climaradtranwrk_fdn_n_get(p, nz+1, self%wrk_ir%fdn_n)
-    if (self%sync_spectra) then
-      call c_climaradtranwrk_fup_a_get(p, nz+1, self%ir%nw, self%wrk_ir%fup_a)
-      call c_climaradtranwrk_fdn_a_get(p, nz+1, self%ir%nw, self%wrk_ir%fdn_a)
-      call c_climaradtranwrk_tau_band_get(p, nz, self%ir%nw, self%wrk_ir%tau_band)
-    endif
     if (do_solar) then
       call c_radtran_wrk_sol_get(self%handle, p)
       call c_climaradtranwrk_fup_n_get(p, nz+1, self%wrk_sol%fup_n)
       call c_climaradtranwrk_fdn_n_get(p, nz+1, self%wrk_sol%fdn_n)
-      if (self%sync_spectra) then
-        call c_climaradtranwrk_fup_a_get(p, nz+1, self%sol%nw, self%wrk_sol%fup_a)
-        call c_climaradtranwrk_fdn_a_get(p, nz+1, self%sol%nw, self%wrk_sol%fdn_a)
-        call c_climaradtranwrk_amean_get(p, nz+1, self%sol%nw, self%wrk_sol%amean)
-        call c_climaradtranwrk_tau_band_get(p, nz, self%sol%nw, self%wrk_sol%tau_band)
-      endif
+    endif
+    if (self%sync_spectra) then
+      ! the seven per-bin arrays in one go: page-locked on first use, asynchronous copies, one synchronise
+      ! (the reference's holder is plain allocatables the caller reads after the call, clima_radtran.f90:11-25)
+      ds = do_solar
+      call c_radtran_spectra_get_all(self%handle, ds, nz+1, self%ir%nw, self%sol%nw, &
+                                     self%wrk_ir%fup_a, self%wrk_ir%fdn_a, self%wrk_ir%tau_band, &
+                                     self%wrk_sol%fup_a, self%wrk_sol%fdn_a, self%wrk_sol%amean, self%wrk_sol%tau_band, err_c)
     endif
     call c_radtran_f_total_get(self%handle, nz+1, self%f_total)
   end subroutine
@@ -787,7 +798,10 @@ contains
 
   subroutine Radtran_destroy(self)
     class(Radtran), intent(inout) :: self
-    if (c_associated(self%handle)) call c_deallocate_radtran(self%handle)
+    if (c_associated(self%handle)) then
+      call c_radtran_spectra_release(self%handle)   ! the result arrays are no longer page-locked: they may be freed
+      call c_deallocate_radtran(self%handle)
+    endif
     self%handle = c_null_ptr
   end subroutine
 

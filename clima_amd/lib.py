@@ -50,6 +50,8 @@ SIGNATURES = {
     "radtran_coop_items_get": [_vp, _ip],
     "radtran_fused_spins_set": [_vp, _ip],
     "radtran_fused_spins_get": [_vp, _ip],
+    "radtran_spectra_get_all": [_vp, _bp, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],
+    "radtran_spectra_release": [_vp],
     "radtran_toa_fluxes_batch": [_vp, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _err],
     "radtran_radiate_ir_batch": [_vp, _ip, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _err],
     "radtran_upload_column": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],

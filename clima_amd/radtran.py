@@ -166,6 +166,8 @@ class Radtran:
 
     def __del__(self):
         if getattr(self, "_ptr", None) is not None and self._ptr.value:
+            if getattr(self, "_locked", None):
+                self._L.radtran_spectra_release(self._ptr)
             self._L.deallocate_radtran(self._ptr)
             self._ptr = C.c_void_p()
 
@@ -414,6 +416,32 @@ class Radtran:
     @coop_items.setter
     def coop_items(self, n):
         self._L.radtran_coop_items_set(self._ptr, _i(int(n)))
+
+    def spectra_all(self, do_solar=True, out=None):
+        """The seven per-bin arrays of the last call through radtran_spectra_get_all (one synchronise; the arrays of
+        `out` -- a dict from an earlier call -- are page-locked by the library on first use).  Column-major like the
+        reference's holders: fup_a, fdn_a (nz+1, nw), tau_band (nz, nw) per channel, amean for the solar one."""
+        nl, ni, ns = self.nz + 1, len(self.ir.freq) - 1, len(self.sol.freq) - 1
+        if out is None:
+            out = {"ir_fup_a": np.zeros((nl, ni), order="F"), "ir_fdn_a": np.zeros((nl, ni), order="F"),
+                   "ir_tau_band": np.zeros((nl - 1, ni), order="F"), "sol_fup_a": np.zeros((nl, ns), order="F"),
+                   "sol_fdn_a": np.zeros((nl, ns), order="F"), "sol_amean": np.zeros((nl, ns), order="F"),
+                   "sol_tau_band": np.zeros((nl - 1, ns), order="F")}
+        err = C.create_string_buffer(1025)
+        names = ("ir_fup_a", "ir_fdn_a", "ir_tau_band", "sol_fup_a", "sol_fdn_a", "sol_amean", "sol_tau_band")
+        self._L.radtran_spectra_get_all(self._ptr, C.byref(C.c_bool(bool(do_solar))), _i(nl), _i(ni), _i(ns),
+                                        *[out[k].ctypes.data_as(C.POINTER(C.c_double)) for k in names], err)
+        if err.value:
+            raise ClimaException(err.value.decode())
+        self._locked = getattr(self, "_locked", [])
+        if not any(o is out for o in self._locked):
+            self._locked.append(out)          # page-locked by the library: kept alive until spectra_release / the handle goes
+        return out
+
+    def spectra_release(self):
+        """Un-page-lock what spectra_all locked (before those arrays are freed)."""
+        self._L.radtran_spectra_release(self._ptr)
+        self._locked = []
 
     @property
     def fused_spins(self):
