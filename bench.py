@@ -479,61 +479,73 @@ def main():
 
 def probe_native(rad, col, nz, world, rank, dist, torch, json_fd):
     """The library-owned RCCL step on the job's ranks, checked against torch's all-reduce of the same partial rows:
-    a full step, an IR-only step on the stored opacities (the partial solar rows are put back before the reduce),
-    and a forced hand-off timeout on rank 0 (radtran_fused_spins_set(0): the status word makes every rank repeat the
-    step).  Rank 0 prints `native step ok` when every row agrees to 1e-13 of its maximum on every rank."""
+    a full step and an IR-only step on the stored opacities (the partial solar rows are put back before the reduce)
+    on the benchmark's own handle, then -- on a smaller spectrum (400 bins, 4 zenith angles: there two-stream blocks of
+    the fused grid do find their tiles unfinished) -- a step with every hand-off wait of rank 0 made to expire
+    (radtran_fused_spins_set(0)): the status word that rides on the all-reduce makes every rank repeat the step.
+    Rank 0 prints `native step ok` when every row agrees to 1e-13 of its maximum on every rank."""
     import numpy as np
+    from clima_amd import synthetic as S
     from clima_amd.radtran import Radtran
 
     def rows(r):
         return np.concatenate([np.asarray(r.wrk_ir.fup_n), np.asarray(r.wrk_ir.fdn_n), np.asarray(r.wrk_sol.fup_n),
                                np.asarray(r.wrk_sol.fdn_n), np.asarray(r.f_total)])
 
-    # reference: shard + torch all-reduce (host-synchronised: the plainest form)
-    rad.set_bin_shard(rank, world)
-    rad.upload_column(*col.args())
-    flux = rad.flux_tensor()
-    want = []
-    for solar in (True, False):
-        rad.radiate_resident(compute_solar=solar)
-        rad.synchronize()
-        if not solar:   # the reduced solar rows of the step before are overwritten by this rank's share again
-            pass
-        dist.all_reduce(flux)
-        torch.cuda.synchronize()
-        rad.finish_reduced()
-        want.append(rows(rad))
-    rad.set_bin_shard(0, 1)
-    # the library's own step on a fresh handle state
-    ids = [Radtran.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(ids, src=0)
-    rad.comm_init_rank(world, rank, ids[0])
-    rad.upload_column(*col.args())
+    def by_torch(r, steps):
+        """shard + torch all-reduce, host-synchronised: the plainest form"""
+        r.set_bin_shard(rank, world)
+        r.upload_column(*col.args())
+        flux = r.flux_tensor()
+        out = []
+        for solar in steps:
+            r.radiate_resident(compute_solar=solar)
+            r.synchronize()
+            dist.all_reduce(flux)
+            torch.cuda.synchronize()
+            r.finish_reduced()
+            out.append(rows(r))
+        r.set_bin_shard(0, 1)
+        return out
+
+    def attach(r):
+        ids = [Radtran.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        r.comm_init_rank(world, rank, ids[0])
+        r.upload_column(*col.args())
+
+    want = by_torch(rad, (True, False))
+    attach(rad)
     got = []
     for solar in (True, False):
         rad.radiate_resident(compute_solar=solar)
         rad.synchronize()
         got.append(rows(rad))
-    n0 = rad.fused_fallbacks
-    spins = rad.fused_spins
-    if rank == 0:
-        rad.fused_spins = 0
-    rad.radiate_resident()
-    rad.synchronize()
-    rad.fused_spins = spins
-    got.append(rows(rad))
-    want.append(want[0])
-    err = max(float(np.max(np.abs(g - w)) / np.max(np.abs(w))) for g, w in zip(got, want))
-    t = torch.tensor([err], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    err = float(t[0])
     rad.synchronize()
     dist.barrier()
     rad.comm_destroy()
+    # the forced repeat
+    small = Radtran(S.modern_earth_tables(nw=400), nz, 4, 0.2)
+    want += by_torch(small, (True,))
+    attach(small)
+    n0 = small.fused_fallbacks
+    if rank == 0:
+        small.fused_spins = 0
+    small.radiate_resident()
+    small.synchronize()
+    got.append(rows(small))
+    repeats = small.fused_fallbacks - n0
+    small.synchronize()
+    dist.barrier()
+    small.comm_destroy()
+    err = max(float(np.max(np.abs(g - w)) / np.max(np.abs(w))) for g, w in zip(got, want))
+    t = torch.tensor([err, float(repeats)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    err, repeats = float(t[0]), int(t[1])
     dist.destroy_process_group()
     if rank == 0:
         msg = "native step %s: largest difference from torch's all-reduce %.2e of a row's maximum on %d ranks, repeated steps %d\n" % (
-            "ok" if err < 1e-13 else "DIFFERS", err, world, rad.fused_fallbacks - n0)
+            "ok" if err < 1e-13 else "DIFFERS", err, world, repeats)
         os.write(json_fd, msg.encode())
     if err >= 1e-13:
         sys.exit(3)

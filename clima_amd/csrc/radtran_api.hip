@@ -1717,7 +1717,11 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     // not with a base that is not a number anywhere (every column would "deviate" there and inherit it), nor when the
     // work arrays (~150 KB per (bin, g-point) at 500 layers) would take more than 16 GB
     for (double v : pl.base) if (!std::isfinite(v)) green = false;
-    if ((double)r->ir_n * r->ng * (13.0 * nl + 14.0 * nz + 4.3 * nl) * 8.0 > 16.0e9) green = false;
+    // (the partial sums of the two accumulation kernels are part of that: at most (64 + bins) splits x deviations x 2 x levels)
+    if (((double)r->ir_n * r->ng * (13.0 * nl + 14.0 * nz + 4.3 * nl) +
+         (64.0 + r->ir_n) * ((double)pl.dev_k.size() + 64.0) * 2.0 * nl) * 8.0 > 16.0e9) green = false;
+    // k_green_unit / k_green_local take one (bin, g-point) pair per blockIdx.y: a grid dimension of at most 65535
+    if ((long)r->ir_n * r->ng > 65535) green = false;
     if (green) ir_batch_green(r, pl, T, T_surface, n, r->d_bout.p);
   }
   if (!green) {
@@ -2018,19 +2022,38 @@ void clima_bench_resident_graph(void *ptr, const int *n, const int *k, double *u
   radtran_radiate_resident(ptr, &one, &one, err);     // steady state: buffers allocated, fields uploaded
   if (err && err[0]) return;
   HIPCHK(hipStreamSynchronize(r->stream));
+  // (nothing that synchronises or allocates may run inside the capture: stale fields are uploaded by the call above;
+  // per-kernel event profiling records events of its own)
+  if (r->fields_dirty || r->profile != 0) throw HipFail{"clima_bench_resident_graph: not with stale fields or profiling on"};
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   HIPCHK(hipStreamBeginCapture(r->stream, hipStreamCaptureModeThreadLocal));
-  enqueue_radiate(r, true, true);
+  try {
+    enqueue_radiate(r, true, true);
+  } catch (...) {
+    // a failure inside the captured section must not leave the handle's stream in capture mode (every later call
+    // on it would fail): close the capture, drop what was captured, pass the error on
+    hipGraph_t g2 = nullptr;
+    (void)hipStreamEndCapture(r->stream, &g2);
+    if (g2) (void)hipGraphDestroy(g2);
+    (void)hipGetLastError();
+    throw;
+  }
   HIPCHK(hipStreamEndCapture(r->stream, &graph));
-  HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-  for (int i = 0; i < 10; i++) HIPCHK(hipGraphLaunch(exec, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
-  for (int i = 0; i < *n; i++) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int j = 0; j < std::max(1, *k); j++) HIPCHK(hipGraphLaunch(exec, r->stream));
+  try {
+    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < 10; i++) HIPCHK(hipGraphLaunch(exec, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream));
-    us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    for (int i = 0; i < *n; i++) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int j = 0; j < std::max(1, *k); j++) HIPCHK(hipGraphLaunch(exec, r->stream));
+      HIPCHK(hipStreamSynchronize(r->stream));
+      us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+  } catch (...) {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    throw;
   }
   (void)hipGraphExecDestroy(exec);
   (void)hipGraphDestroy(graph);
@@ -2154,27 +2177,48 @@ void radtran_comm_init_file(void *ptr, const int *nranks, const int *rank, const
   TRY
   char id[CLIMA_COMM_ID_BYTES];
   const std::string file(path), tmp = file + ".tmp";
+  // What is published is a record, not the bare id: magic, the communicator's size and a job nonce (CLIMA_COMM_NONCE,
+  // else SLURM_JOB_ID, else empty) in front of it.  A rank other than 0 joins only on a record whose size and nonce are
+  // its own -- a leftover of a crashed or re-launched job on the same path (which rank 0 also removes before it
+  // publishes) is not taken for this job's id, and a rank that finds nothing valid in time returns an error instead of
+  // blocking in ncclCommInitRank on a dead id.  Without a nonce the file's age is the only guard (60 s against this
+  // call's start, by this host's clock): hosts sharing a path across jobs should set one.
+  struct Record { char magic[8]; int nranks; char nonce[64]; char id[CLIMA_COMM_ID_BYTES]; } rec;
+  std::memset(&rec, 0, sizeof(rec));
+  std::memcpy(rec.magic, "CLRCOMM1", 8);
+  rec.nranks = *nranks;
+  const char *nonce = getenv("CLIMA_COMM_NONCE");
+  if (!nonce || !nonce[0]) nonce = getenv("SLURM_JOB_ID");
+  if (nonce) std::strncpy(rec.nonce, nonce, sizeof(rec.nonce) - 1);
   if (*rank == 0) {
+    (void)std::remove(file.c_str());   // whatever an earlier job left there
     ncclUniqueId u;
     NCCLCHK(ncclGetUniqueId(&u));
     std::memcpy(id, &u, sizeof(u));
+    std::memcpy(rec.id, id, sizeof(id));
     FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0 || std::rename(tmp.c_str(), file.c_str()) != 0)
+    if (!f || std::fwrite(&rec, 1, sizeof(rec), f) != sizeof(rec) || std::fclose(f) != 0 || std::rename(tmp.c_str(), file.c_str()) != 0)
       throw HipFail{"radtran_comm_init_file: cannot write " + file};
   } else {
-    bool got = false;
+    bool got = false, stale = false;
     const time_t t_enter = time(nullptr);
     for (int tries = 0; tries < 6000 && !got; tries++) {   // up to ~120 s
       struct stat st;
-      // (a file much older than this call is a crashed job's leftover, not this job's id: keep waiting for rank 0)
-      if (stat(file.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(id) && st.st_mtime >= t_enter - 600) {
+      if (stat(file.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(rec)) {
+        Record got_rec;
         FILE *f = std::fopen(file.c_str(), "rb");
-        got = f && std::fread(id, 1, sizeof(id), f) == sizeof(id);
+        const bool read_ok = f && std::fread(&got_rec, 1, sizeof(got_rec), f) == sizeof(got_rec);
         if (f) std::fclose(f);
+        const bool mine = read_ok && std::memcmp(got_rec.magic, rec.magic, 8) == 0 && got_rec.nranks == rec.nranks &&
+                          std::memcmp(got_rec.nonce, rec.nonce, sizeof(rec.nonce)) == 0 &&
+                          (rec.nonce[0] || st.st_mtime >= t_enter - 60);
+        if (mine) { std::memcpy(id, got_rec.id, sizeof(id)); got = true; }
+        else if (read_ok) stale = true;
       }
       if (!got) usleep(20000);
     }
-    if (!got) throw HipFail{"radtran_comm_init_file: rank 0 did not publish " + file};
+    if (!got) throw HipFail{std::string("radtran_comm_init_file: rank 0 did not publish a record for this job at ") + file +
+                            (stale ? " (a record of another job, communicator size or nonce is there)" : "")};
   }
   comm_attach(r, *nranks, *rank, id);   // collective: returns once every rank has joined
   if (*rank == 0) (void)std::remove(file.c_str());

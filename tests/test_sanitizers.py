@@ -32,8 +32,10 @@ def test_oracle_c_driver_under_asan_ubsan_lsan(tmp_path):
 
 
 def test_the_full_sanitizer_pass_left_a_clean_log():
-    log = os.path.join(ROOT, "profiles", "r03_sanitize.log")
+    log = os.path.join(ROOT, "profiles", "r04_sanitize.log")
     assert os.path.exists(log), "run tools/sanitize.sh"
     text = open(log).read()
     assert "SANITIZE: clean" in text and "abi_driver: ok" in text and "oracle_driver: ok" in text
     assert "ERROR: AddressSanitizer" not in text and "runtime error:" not in text
+    # nothing else may have shouted either (round 3's log held an RCCL "[FATAL ERROR]" that no check looked at)
+    assert "FATAL" not in text.upper().replace("HALT_ON_ERROR", ""), [l for l in text.splitlines() if "FATAL" in l.upper()]

@@ -127,7 +127,10 @@ int main(void) {
     radtran_set_bin_shard(h, &one, &one, err);
     expect(err[0] != 0, "invalid shard / unconstructed refused");
     char id[CLIMA_COMM_ID_BYTES];
-    radtran_comm_unique_id(id, err);
+    memset(id, 0, sizeof(id));
+    /* a communicator id is drawn only where a device exists: without one RCCL itself prints a FATAL line to stderr
+       (this container has none: the call below then only has to reach the "not constructed" refusal) */
+    if (constructed) radtran_comm_unique_id(id, err);
     radtran_comm_init_rank(h, &one, &n2, id, err);
     if (!constructed) expect(strstr(err, "not constructed") != NULL, "communicator on an unconstructed handle refused");
     radtran_comm_destroy(h);
@@ -136,6 +139,19 @@ int main(void) {
     radtran_set_custom_optical_properties(h, &i3, wv, &i3, Pc, &i2, &i3, t9, &i3, &i3, t9, &i3, &i3, t9, err);
     expect(err[0] != 0, "custom optical properties: bad shape / unconstructed refused");
     radtran_unset_custom_optical_properties(h);
+    {
+      /* round 4: all spectra in one go (refused on an unconstructed handle, extents checked), its release, the spin bound */
+      bool ds = true;
+      int nl = 3, nwi = NW - 3, nws = 2;
+      double a7[7][64];
+      radtran_spectra_get_all(h, &ds, &nl, &nwi, &nws, a7[0], a7[1], a7[2], a7[3], a7[4], a7[5], a7[6], err);
+      expect(err[0] != 0, "spectra_get_all: unconstructed handle / wrong extents refused");
+      radtran_spectra_release(h);
+      int sp = 0;
+      radtran_fused_spins_set(h, &sp);
+      radtran_fused_spins_get(h, &sp);
+      expect(sp == 0, "fused_spins round trip");
+    }
     deallocate_radtran(h);
   }
   deallocate_radtran(NULL);

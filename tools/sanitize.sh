@@ -7,10 +7,10 @@
 #   2. the host side of libclima_radtran_hip.so with hipcc's host-only AddressSanitizer + UBSan
 #      (-fsanitize=address,undefined -fno-gpu-sanitize): a C driver through construction, every validation / error
 #      path, getters / setters and destruction, then tests/test_abi.py against that build.
-# Writes profiles/r03_sanitize.log; exit code 0 = no report.
+# Writes profiles/r04_sanitize.log; exit code 0 = no report.
 set -o pipefail
 cd "$(dirname "$0")/.."
-LOG=profiles/r03_sanitize.log
+LOG=profiles/r04_sanitize.log
 : > $LOG
 say() { echo "== $*" | tee -a $LOG; }
 fail() { echo "SANITIZE: FAILED at: $*" | tee -a $LOG; exit 1; }
