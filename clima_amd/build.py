@@ -6,7 +6,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libclima_radtran_hip.so")
-SOURCES = ["kernels.hip", "radtran_api.hip"]
+SOURCES = ["kernels.hip", "radtran_api.hip", "radtran_loader.hip"]
 DEPS = SOURCES + ["radtran_dev.h", "sort_network_64.inc", "rorr_xys_asm.inc", "ir_green.inc", os.path.join("..", "..", "include", "clima_radtran_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # The kernels take their parameter blocks by value; hipcc reads them straight from the kernel-argument
@@ -17,7 +17,7 @@ LLVM_FLAGS = ["-mllvm", "-instcombine-max-copied-from-constant-users=100000"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"] + LLVM_FLAGS
 # RCCL: the bin-sharded step's all-reduce is issued by the library itself (radtran_comm_init_rank).  In a process
 # that imported torch first, the loader resolves librccl.so.1 to the copy torch has already mapped (same SONAME).
-LIBS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+LIBS = ["-L/opt/rocm/lib", "-lrccl", "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
 
 
 def is_stale():
@@ -40,6 +40,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
 
 FORTRAN_DIR = os.path.join(_HERE, "fortran")
 FORTRAN_DRIVER = os.path.join(FORTRAN_DIR, "radtran_driver")
+FORTRAN_FROM_FILES = os.path.join(FORTRAN_DIR, "radtran_from_files")   # the constructor-from-files host (radtran_from_files.f90)
 FLANG = os.environ.get("FLANG", "/opt/rocm/bin/amdflang")
 
 
@@ -50,15 +51,17 @@ def build_fortran_shim(verbose=False):
         if verbose:
             print("amdflang not found: skipping the Fortran shim")
         return None
-    srcs = [os.path.join(FORTRAN_DIR, "clima_radtran_hip.f90"), os.path.join(FORTRAN_DIR, "radtran_driver.f90")]
-    if os.path.exists(FORTRAN_DRIVER) and all(os.path.getmtime(FORTRAN_DRIVER) > os.path.getmtime(x)
-                                              for x in srcs + [LIB]):
-        return FORTRAN_DRIVER
-    cmd = [FLANG, "-O2", "-J", FORTRAN_DIR] + srcs + ["-o", FORTRAN_DRIVER, "-L" + CSRC, "-lclima_radtran_hip",
-                                                      "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    mod = os.path.join(FORTRAN_DIR, "clima_radtran_hip.f90")
+    progs = [(FORTRAN_DRIVER, os.path.join(FORTRAN_DIR, "radtran_driver.f90")),
+             (FORTRAN_FROM_FILES, os.path.join(FORTRAN_DIR, "radtran_from_files.f90"))]
+    for exe, src in progs:
+        if os.path.exists(exe) and all(os.path.getmtime(exe) > os.path.getmtime(x) for x in (mod, src, LIB)):
+            continue
+        cmd = [FLANG, "-O2", "-J", FORTRAN_DIR, mod, src, "-o", exe, "-L" + CSRC, "-lclima_radtran_hip",
+               "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return FORTRAN_DRIVER
 
 

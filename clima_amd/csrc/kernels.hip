@@ -879,6 +879,10 @@ __device__ __forceinline__ void opacity8_body(const OpacityParams &p, const int 
   // is in this load-latency-bound part while the other is in the VALU-bound sort/rebin, instead of
   // both stalling on memory at the same time.
   auto layer_terms = [&](const int jl, LayerTerms &o) {
+#ifdef CLIMA_EXP_NOTERMS   // timing experiment only (WRONG results): what the tile costs without its layer terms
+    o.tausg = 1e-3; o.taua = 1e-3; o.tauc = TINY; o.tausc = TINY * TINY; o.taup = 0.0; o.tausp = 0.0; o.gt = 0.0;
+    if (jl >= 0) return;
+#endif
     const double dzj = c.dz[oc + jl];
     // ---- Rayleigh (:686-693)
     double tausg = 0.0;

@@ -2693,6 +2693,58 @@ void radtran_photons_sol_get(void *ptr, const int *dim1, double *arr) {
   for (int i = 0; i < *dim1 && i < (int)r->photons_sol.size(); i++) arr[i] = r->photons_sol[i];
 }
 
+// extents of a handle (whatever built it): layers, gases, particles, opacity bins, g-points
+void radtran_dims_get(void *ptr, int *nz, int *nsp, int *np, int *nw, int *ngauss) {
+  Radtran *r = as_rad(ptr);
+  *nz = r ? r->nz : 0; *nsp = r ? r->nsp : 0; *np = r ? r->np : 0; *nw = r ? r->nw : 0; *ngauss = r ? r->ng : 0;
+}
+// the species / particle names the handle holds (radtran_set_names), newline-separated, into caller buffers of `cap` bytes
+void radtran_names_get(void *ptr, const int *cap, char *species_names, char *particle_names) {
+  Radtran *r = as_rad(ptr);
+  auto put = [&](const std::vector<std::string> &v, char *out) {
+    std::string o;
+    for (size_t i = 0; i < v.size(); i++) o += (i ? "\n" : "") + v[i];
+    std::strncpy(out, o.c_str(), (size_t)std::max(*cap - 1, 0));
+    if (*cap > 0) out[*cap - 1] = 0;
+  };
+  if (r) { put(r->species_names, species_names); put(r->particle_names, particle_names); }
+  else if (*cap > 0) { species_names[0] = 0; particle_names[0] = 0; }
+}
+
+// Test hook: FNV-1a (64 bit) over the handle's HOST-side tables in the order they were handed over -- metadata as
+// int32, values as float64 bytes.  The from-files loader (radtran_loader.hip) is held to clima_amd/data_loader.py with
+// it where there is no device: identical tables <=> identical digests (tests/test_loader_cabi.py).
+void clima_test_host_tables_digest(void *ptr, unsigned long long *digest) {
+  // digest[0..7]: extents + opacity grid | k-tables | CIA | Rayleigh | absorption / photolysis | continuum | particles |
+  // channels + stellar photons (each hash starts afresh: a difference names its group)
+  Radtran *r = as_rad(ptr);
+  unsigned long long h = 0;
+  auto start = [&] { h = 1469598103934665603ULL; };
+  auto bytes = [&](const void *p0, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p0);
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ULL; }
+  };
+  auto ints = [&](std::initializer_list<int> v) { for (int x : v) bytes(&x, sizeof(int)); };
+  auto vals = [&](const std::vector<double> &v) { if (!v.empty()) bytes(v.data(), v.size() * sizeof(double)); };
+  for (int g = 0; g < 8; g++) digest[g] = 0;
+  if (!r) return;
+  start(); ints({r->nz, r->nsp, r->np, r->nw}); vals(r->wavl); digest[0] = h;
+  start();
+  for (auto *k : r->k) { ints({k->sp, k->ng, k->nP, k->nT}); vals(k->weights); vals(k->log10P); vals(k->temp); vals(k->log10k); }
+  digest[1] = h;
+  int g = 2;
+  for (auto *lst : {&r->cia, &r->ray, &r->pxs}) {
+    start();
+    for (auto *x : *lst) { ints({x->type, x->dim, x->sp1, x->sp2, x->nT}); vals(x->temp); vals(x->data); }
+    digest[g++] = h;
+  }
+  start(); ints({r->has_cont ? 1 : 0, r->LH2O, r->cont_nT}); vals(r->cont_temp); vals(r->cont_H2O); vals(r->cont_foreign); digest[5] = h;
+  start();
+  for (auto *q : r->part) { ints({q->p_ind, q->nrad}); vals(q->radii); vals(q->w0); vals(q->qext); vals(q->gt); }
+  digest[6] = h;
+  start(); vals(r->ir.wavl); vals(r->sol.wavl); vals(r->photons_sol); digest[7] = h;
+}
+
 // ---- all per-bin spectra of the last call in one go ------------------------------------
 // The reference's result holder is plain allocatables the caller reads after every call (clima_radtran.f90:11-25); a
 // host that does the same through the seven reference-named getters pays seven synchronous copies to pageable memory

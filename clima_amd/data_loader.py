@@ -41,6 +41,19 @@ RDELTA = 1.0e-4
 XS_CIA, XS_RAYLEIGH, XS_ABSORPTION, XS_PHOTOLYSIS = 0, 1, 2, 3
 
 
+def _pow10(a):
+    """10**a through the C library's pow, element by element: numpy's vectorised power / log10 may be SIMD routines
+    of their own that differ from libm in the last bit (and from host to host), and the loader behind the C ABI
+    (csrc/radtran_loader.hip) has to produce the same tables bit for bit."""
+    import math
+    return np.array([math.pow(10.0, float(v)) for v in np.asarray(a, dtype=float).ravel()]).reshape(np.shape(a))
+
+
+def _log10(a):
+    import math
+    return np.array([math.log10(float(v)) for v in np.asarray(a, dtype=float).ravel()]).reshape(np.shape(a))
+
+
 # --------------------------------------------------------------------------- futils restatements
 def addpnt(x, y, xnew, ynew):
     """futils/TUV `addpnt`: insert (xnew, ynew) into the ascending table (x, y).  A point that is
@@ -117,9 +130,13 @@ def interp_discrete_to_bins(wavl, x, y, mode, fill_value=None):
 
 
 def rayleigh_vardavas(A, B, Delta, lam_nm):
-    """src/clima_eqns.f90:240-246"""
-    return (4.577e-21 * ((6.0 + 3.0 * Delta) / (6.0 - 7.0 * Delta)) *
-            (A * (1.0 + B / (lam_nm * 1.0e-3) ** 2.0)) ** 2.0 * (1.0 / (lam_nm * 1.0e-3) ** 4.0))
+    """src/clima_eqns.f90:240-246 (the powers through the C library's pow, element by element: see _pow10)"""
+    import math
+    lam = np.asarray(lam_nm, dtype=float)
+    out = np.array([(4.577e-21 * ((6.0 + 3.0 * Delta) / (6.0 - 7.0 * Delta)) *
+                     math.pow(A * (1.0 + B / math.pow(float(v) * 1.0e-3, 2.0)), 2.0) * (1.0 / math.pow(float(v) * 1.0e-3, 4.0)))
+                    for v in lam.ravel()])
+    return out.reshape(lam.shape) if lam.ndim else float(out[0])
 
 
 # --------------------------------------------------------------------------- pieces
@@ -209,7 +226,7 @@ def read_h5_xsection(filename, wavl, xs_type, sp1, sp2=-1):
             r = _pad_and_bin(wavl, wav_f, h.read("log10xs"), LOG10TINY)
             if r is None:
                 raise ClimaException('Problem interpolating data in "%s"' % filename.strip())
-            return dict(xs_type=xs_type, dim=0, sp1=sp1, sp2=sp2, temp=None, data=10.0 ** r)
+            return dict(xs_type=xs_type, dim=0, sp1=sp1, sp2=sp2, temp=None, data=_pow10(r))
         _check_dataset(h, "T", 1, filename)
         temp = h.read("T")
         _check_dataset(h, "log10xs", 2, filename)
@@ -257,9 +274,9 @@ def read_photolysis_xsection(filename, sp, sp_ind, wavl):
         wv = h.read("wavelengths")
         _check_dataset(h, "photoabsorption", 1, filename)
         xs = h.read("photoabsorption")
-    xs = np.log10(np.maximum(xs, np.finfo(np.float64).tiny))
+    xs = _log10(np.maximum(xs, np.finfo(np.float64).tiny))
     return dict(xs_type=XS_PHOTOLYSIS, dim=0, sp1=sp_ind, sp2=-1, temp=None,
-                data=10.0 ** interp_discrete_to_bins(wavl, wv, xs, "FillValue", LOG10TINY))
+                data=_pow10(interp_discrete_to_bins(wavl, wv, xs, "FillValue", LOG10TINY)))
 
 
 def read_particle_xsection(filename, p_ind, dat_name, wavl):

@@ -338,6 +338,23 @@ module clima_radtran_hip
       real(c_double), intent(out) :: sol_fup_a(*), sol_fdn_a(*), sol_amean(*), sol_tau_band(*)
       character(c_char), intent(out) :: err(*)
     end subroutine
+    subroutine c_radtran_create_from_files(ptr, settings_file, star_file, num_zenith_angles, surface_albedo, nz, datadir, err) &
+        bind(c, name="radtran_create_from_files")
+      import; type(c_ptr), value :: ptr
+      character(c_char), intent(in) :: settings_file(*), star_file(*), datadir(*)
+      integer(c_int), intent(in) :: num_zenith_angles, nz
+      real(c_double), intent(in) :: surface_albedo
+      character(c_char), intent(out) :: err(*)
+    end subroutine
+    subroutine c_radtran_dims_get(ptr, nz, nsp, np, nw, ngauss) bind(c, name="radtran_dims_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(out) :: nz, nsp, np, nw, ngauss
+    end subroutine
+    subroutine c_radtran_photons_sol_get(ptr, dim1, arr) bind(c, name="radtran_photons_sol_get")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: dim1
+      real(c_double), intent(out) :: arr(*)
+    end subroutine
     subroutine c_radtran_spectra_release(ptr) bind(c, name="radtran_spectra_release")
       import; type(c_ptr), value :: ptr
     end subroutine
@@ -381,6 +398,14 @@ module clima_radtran_hip
       integer(c_int), intent(in) :: dim1
       real(c_double), intent(out) :: arr(*)
     end subroutine
+  end interface
+
+  !> `rad = Radtran(settings_f, star_f, num_zenith_angles, surface_albedo, nz, datadir, err)`: the reference's constructor
+  !> (src/radtran/clima_radtran.f90:98-126) with the files read behind the C ABI (radtran_create_from_files: the
+  !> settings YAML's optical-properties block, the stellar spectrum, a photochem_clima_data-style directory), for hosts
+  !> that do not link the reference's own loaders (src/radtran/clima_radtran_types_create.f90).
+  interface Radtran
+    module procedure :: create_Radtran_from_files
   end interface
 
 contains
@@ -499,12 +524,20 @@ contains
     real(dp), intent(in) :: surface_albedo
     character(:), allocatable, intent(out) :: err
     character(c_char) :: err_c(err_len+1)
-    type(c_ptr) :: p
-    integer(c_int) :: n
-    integer :: nz
     call c_radtran_create_end(self%handle, num_zenith_angles, surface_albedo, err_c)
     call take_err(err_c, err)
     if (allocated(err)) return
+    call adopt_handle(self, num_zenith_angles, surface_albedo)
+  end subroutine
+
+  !> the module's side of a constructed handle: public fields and result arrays (clima_radtran.f90:160-214)
+  subroutine adopt_handle(self, num_zenith_angles, surface_albedo)
+    class(Radtran), intent(inout) :: self
+    integer, intent(in) :: num_zenith_angles
+    real(dp), intent(in) :: surface_albedo
+    type(c_ptr) :: p
+    integer(c_int) :: n
+    integer :: nz
     nz = self%nz
     allocate(self%zenith_u(num_zenith_angles), self%zenith_weights(num_zenith_angles))
     call c_radtran_zenith_u_get(self%handle, num_zenith_angles, self%zenith_u)
@@ -537,6 +570,39 @@ contains
       w%fup_a = 0.0_dp; w%fdn_a = 0.0_dp; w%amean = 0.0_dp; w%tau_band = 0.0_dp; w%fup_n = 0.0_dp; w%fdn_n = 0.0_dp
     end subroutine
   end subroutine
+
+  function create_Radtran_from_files(settings_f, star_f, num_zenith_angles, surface_albedo, nz, datadir, err) result(rad)
+    character(*), intent(in) :: settings_f, star_f, datadir
+    integer, intent(in) :: num_zenith_angles, nz
+    real(dp), intent(in) :: surface_albedo
+    character(:), allocatable, intent(out) :: err
+    type(Radtran) :: rad
+    character(c_char) :: err_c(err_len+1)
+    integer(c_int) :: nz_c, nsp, np, nw, ngauss
+    call c_allocate_radtran(rad%handle)
+    call c_radtran_create_from_files(rad%handle, cstr(settings_f), cstr(star_f), int(num_zenith_angles, c_int), surface_albedo, &
+                                     int(nz, c_int), cstr(datadir), err_c)
+    call take_err(err_c, err)
+    if (allocated(err)) then
+      call c_deallocate_radtran(rad%handle)
+      rad%handle = c_null_ptr
+      return
+    endif
+    call c_radtran_dims_get(rad%handle, nz_c, nsp, np, nw, ngauss)
+    rad%nz = nz_c; rad%ng = nsp; rad%np = np
+    call adopt_handle(rad, num_zenith_angles, surface_albedo)
+    call c_radtran_photons_sol_get(rad%handle, size(rad%photons_sol), rad%photons_sol)   ! what the star file gave
+  contains
+    function cstr(s) result(c)
+      character(*), intent(in) :: s
+      character(c_char) :: c(len_trim(s)+1)
+      integer :: i
+      do i = 1, len_trim(s)
+        c(i) = s(i:i)
+      enddo
+      c(len_trim(s)+1) = c_null_char
+    end function
+  end function
 
   !> the public fields are read on every radiate (clima_radtran.f90:262-313)
   subroutine push_fields(self)

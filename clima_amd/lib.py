@@ -52,6 +52,11 @@ SIGNATURES = {
     "radtran_fused_spins_get": [_vp, _ip],
     "radtran_spectra_get_all": [_vp, _bp, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],
     "radtran_spectra_release": [_vp],
+    "radtran_create_from_files": [_vp, C.c_char_p, C.c_char_p, _ip, _dp, _ip, C.c_char_p, _err],
+    "radtran_load_from_files": [_vp, C.c_char_p, C.c_char_p, _ip, C.c_char_p, _err],
+    "clima_test_host_tables_digest": [_vp, C.POINTER(C.c_ulonglong)],   # 8 digests
+    "radtran_dims_get": [_vp, _ip, _ip, _ip, _ip, _ip],
+    "radtran_names_get": [_vp, _ip, C.c_char_p, C.c_char_p],
     "radtran_toa_fluxes_batch": [_vp, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _err],
     "radtran_radiate_ir_batch": [_vp, _ip, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _err],
     "radtran_upload_column": [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],

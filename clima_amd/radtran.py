@@ -164,6 +164,28 @@ class Radtran:
         from . import data_loader
         return cls(data_loader.load_tables(settings_f, star_f, datadir), nz, num_zenith_angles, surface_albedo)
 
+    @classmethod
+    def from_files_c(cls, settings_f, star_f, num_zenith_angles, surface_albedo, nz, datadir):
+        """The same constructor with the files read BEHIND the C ABI (radtran_create_from_files,
+        clima_amd/csrc/radtran_loader.hip): what a Fortran / C host without the reference's loaders calls."""
+        self = cls.__new__(cls)
+        L = _lib.load()
+        self._L = L
+        self._ptr = C.c_void_p()
+        L.allocate_radtran(C.byref(self._ptr))
+        self._err = C.create_string_buffer(_lib.ERR_LEN + 1)
+        L.radtran_create_from_files(self._ptr, str(settings_f).encode(), str(star_f).encode(), _i(num_zenith_angles),
+                                    _f(surface_albedo), _i(nz), str(datadir).encode(), self._err)
+        self._check()
+        d = [C.c_int() for _ in range(5)]
+        L.radtran_dims_get(self._ptr, *[C.byref(x) for x in d])
+        self.nz, self.ng, self.np, self.nw, self.ngauss = (x.value for x in d)
+        a, b = C.create_string_buffer(4096), C.create_string_buffer(4096)
+        L.radtran_names_get(self._ptr, _i(4096), a, b)
+        self.species_names = [x for x in a.value.decode().split("\n") if x]
+        self.particle_names = [x for x in b.value.decode().split("\n") if x]
+        return self
+
     def __del__(self):
         if getattr(self, "_ptr", None) is not None and self._ptr.value:
             if getattr(self, "_locked", None):

@@ -201,6 +201,20 @@ void radtran_set_opacity_labels(void *ptr, const char *k_method, const char *wat
  * 0 = one launch per kernel.  Same results to rounding; CLIMA_HIP_FUSED=0 sets the default off. */
 void radtran_fused_set(void *ptr, const int *enable);
 void radtran_fused_get(void *ptr, int *enabled);
+/* Construction from files: `Radtran(settings_f, star_f, num_zenith_angles, surface_albedo, nz, datadir, err)`
+ * (src/radtran/clima_radtran.f90:98-126) for hosts that do not link the reference's loaders
+ * (src/radtran/clima_radtran_types_create.f90): the settings YAML's optical-properties block, the stellar spectrum and a
+ * `photochem_clima_data`-style directory (kdistributions/, CIA/, xsections/, water_continuum/, rayleigh/,
+ * aerosol_xsections/) are read on the host (HDF5 C library opened at run time, CLIMA_HDF5_LIB names it) and handed to
+ * radtran_create_begin ... radtran_create_end.  Strings are NUL-terminated; error texts are the reference's.
+ * radtran_load_from_files is the same without the upload (radtran_create_end): the handle is left in the "begun" state. */
+void radtran_create_from_files(void *ptr, const char *settings_file, const char *star_file, const int *num_zenith_angles,
+                               const double *surface_albedo, const int *nz, const char *datadir, char *err);
+void radtran_load_from_files(void *ptr, const char *settings_file, const char *star_file, const int *nz, const char *datadir, char *err);
+/* extents of a handle (layers, gases, particles, opacity bins, g-points) and the names it holds (newline-separated, into
+ * caller buffers of `cap` bytes each): what a host needs to size its arrays after radtran_create_from_files */
+void radtran_dims_get(void *ptr, int *nz, int *nsp, int *np, int *nw, int *ngauss);
+void radtran_names_get(void *ptr, const int *cap, char *species_names, char *particle_names);
 /* All per-bin spectra of the last call in one go: the seven arrays of the two result holders (`ClimaRadtranWrk`,
  * src/radtran/clima_radtran.f90:11-25: fup_a, fdn_a (nz+1, nw), tau_band (nz, nw) per channel, amean for the solar
  * one), column-major as the reference-named getters fill them.  The caller's arrays are page-locked on first use
@@ -278,6 +292,10 @@ void clima_bench_resident_graph(void *ptr, const int *n, const int *k, double *u
 
 /* test hook: y[i] = the kernels' device exp(x[i]) (used where the reference calls exp) */
 void clima_test_device_exp(const int *n, const double *x, double *y, char *err);
+/* FNV-1a (64 bit) over the handle's host-side tables (metadata as int32, values as float64 bytes, in the order they were
+ * handed over), one digest per group -- digest[0..7]: extents + grid, k-tables, CIA, Rayleigh, absorption / photolysis,
+ * continuum, particles, channels + stellar photons: how the from-files loader is held to the Python one without a device */
+void clima_test_host_tables_digest(void *ptr, unsigned long long *digest);
 void clima_test_device_exp_table(const int *n, const int *base10, const double *x, double *y, char *err);
 /* test hook: the device reciprocal with 0, 1 and 2 Newton steps, and the device sqrt of |x|
  * (y: 4 arrays of n) */
