@@ -623,9 +623,6 @@ __device__ __forceinline__ void rebin_window(const double (&key)[64], const bool
 }
 
 #include "rorr_xys_asm.inc"
-#ifdef CLIMA_STAMPS
-#include "rorr_xys_asm_dbg.inc"
-#endif
 #ifndef CLIMA_RORR_ASM
 #define CLIMA_RORR_ASM 1
 #endif
@@ -650,35 +647,17 @@ __device__ __forceinline__ void rorr_mix8(const double (&x)[8], const double (&y
     // x and y ascending (the normal case: k-coefficients ascend in g, and so does a rebinned mixture) with the
     // window-form rebin: the whole step is one block of generated assembly (rorr_xys_asm.inc,
     // tools/gen_rorr_asm.py) that leaves out the merges and the rebin rows the wave's operands make unnecessary.
-    if (xys) {
+    if (__builtin_expect(xys, 1)) {
       double xx[8], yy[8];
 #pragma unroll
       for (int g = 0; g < 8; g++) { xx[g] = x[g]; yy[g] = y[g]; }
       typedef __attribute__((address_space(3))) const double lds_cdouble;
       const unsigned wxy_addr = (unsigned)(unsigned long)(lds_cdouble *)s_wxy;   // 512-byte aligned (opacity8_body)
-#ifdef CLIMA_STAMPS
-      // diagnostic build: the block's own s_memtime samples (start, keys built, sorted, rebinned, end), the rows it
-      // rebinned and its merge mask, for the first wave of every 50th tile
-      int d0, d1, d2, d3, d4, drows, dskip;
-      asm volatile(RORR_XYS_ASM_DBG_TEXT
-                   : "+v"(xx[0]), "+v"(xx[1]), "+v"(xx[2]), "+v"(xx[3]), "+v"(xx[4]), "+v"(xx[5]), "+v"(xx[6]), "+v"(xx[7]),
-                     "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(yy[4]), "+v"(yy[5]), "+v"(yy[6]), "+v"(yy[7])
-                   : "v"(wxy_addr), "s"(rorr_tab)
-                   : RORR_XYS_ASM_DBG_CLOBBERS);
-      asm volatile("s_mov_b32 %0, s98\n\ts_mov_b32 %1, s100\n\ts_mov_b32 %2, s40\n\ts_mov_b32 %3, s44\n\ts_mov_b32 %4, s46\n\t"
-                   "s_mov_b32 %5, s43\n\ts_mov_b32 %6, s42"
-                   : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(drows), "=s"(dskip));
-      if (stamps && tile % 50 == 0 && threadIdx.x == 0) {
-        long long *q = stamps + 7000 + ((tile / 50) * 4 + (stamp_slot - 22)) * 8;
-        q[0] = d0; q[1] = d1; q[2] = d2; q[3] = d3; q[4] = d4; q[5] = drows; q[6] = dskip; q[7] = 1;
-      }
-#else
       asm volatile(RORR_XYS_ASM_TEXT
                    : "+v"(xx[0]), "+v"(xx[1]), "+v"(xx[2]), "+v"(xx[3]), "+v"(xx[4]), "+v"(xx[5]), "+v"(xx[6]), "+v"(xx[7]),
                      "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(yy[4]), "+v"(yy[5]), "+v"(yy[6]), "+v"(yy[7])
                    : "v"(wxy_addr), "s"(rorr_tab)
                    : RORR_XYS_ASM_CLOBBERS);
-#endif
 #pragma unroll
       for (int g = 0; g < 8; g++) out[g] = yy[g];   // the new coefficients come back in the y operands
       STAMP(stamps, stamp_slot);

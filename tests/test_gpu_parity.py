@@ -9,6 +9,16 @@ north_star tolerance: OLR within 1e-4 relative of the reference.  What is enforc
     bounds this at ~3e-14; measured 2.8e-14)
 Differences come from device exp/log10 (<=1 ulp), FMA contraction, reciprocal-multiply in
 the chunked Thomas sweeps, and the summation order of the zenith/g-point weights.
+
+Three DELIBERATE departures from the reference's arithmetic sit inside these tolerances:
+  * the 64 sums of a random-overlap mixing step carry their pair index in mantissa bits 3-8 and that key IS the value
+    that is rebinned (<= 2^-44 relative; clima_amd/csrc/kernels.hip KEY_IDX_MASK);
+  * the fused grid's two-stream part forms w0 = min(0.99999, scat * (1/tau)) with the correctly rounded reciprocal
+    (<= 1 ulp from the quotient of clima_radtran_types.f90:869-875; the stored w0 array is the quotient itself);
+  * round 4: rows of a mixing step that stand alone above everything before them are rebinned as sum_j w_j key(k, j)
+    instead of the difference quotient of the running integral (1e-15 relative, the more accurate of the two) -- which
+    rows do is decided per 64-lane wave, so a lane's last bits depend on its wave-mates
+    (test_mixing_step_with_every_kind_of_wave below forces every case).
 """
 import numpy as np
 import pytest
@@ -863,3 +873,43 @@ def test_half_wave_two_stream_launch_at_16_24_32_g_points(O, ng, nz):
     r2.radiate(*col.args())
     np.testing.assert_array_equal(np.array(r2.f_total), half_ft)            # repeatable bit for bit (atomics of two addends)
     np.testing.assert_array_equal(np.array(r2.wrk_sol.fup_n), half_up)
+
+
+def test_mixing_step_with_every_kind_of_wave(O):
+    """The assembly form of the mixing step (clima_amd/csrc/rorr_xys_asm.inc; reference k_rorr,
+    /root/reference/src/radtran/clima_radtran_types.f90:823-852) decides per 64-lane wave what it may leave out.  The
+    k-tables here are built so that one call meets every case: a species whose whole range lies below the smallest gap of
+    the mixture (row view, every merge left out, every row rebinned in closed form: the sums are already in the
+    reference's order), a dominant species with wide gaps over a narrow mixture (column view), species of comparable
+    size (nothing left out), bins where only the top rows stand alone (some merges, some rows), and -- second handle --
+    g-points in scrambled order (the general network).  All against the oracle at the usual 1e-11 on tau.
+    The closed-form rows differ from the sorted path at the 1e-15 level: which is why this is a
+    tolerance test and not a bitwise one."""
+    from clima_amd import synthetic as S
+    nz = 70
+    for sorted_k in (True, False):
+        tb = S.make_tables(nw=24, seed=77, sorted_k=sorted_k)
+        ng = tb.ng
+        g = np.arange(ng, dtype=float)
+        for bi in range(tb.nw):
+            kind = bi % 4
+            for si, k in enumerate(tb.ktables):
+                a = k["log10k"]                      # [bin][T][P][g]
+                smooth = 0.002 * (k["temp"][:, None] - 300.0) + 0.1 * (k["log10P"][None, :] + 2.0)
+                col_scale = -np.log10({"H2O": 5e22, "CO2": 8e21, "O2": 4.5e24, "O3": 1e19, "CH4": 4e19}[tb.species_names[k["sp_ind"]]])
+                if kind == 0:      # species 0 wide gaps; the others tiny and nearly flat: rows never interleave
+                    base, ramp = (-1.0, 1.0) if si == 0 else (-9.0 - si, 0.004)
+                elif kind == 1:    # species 1 dominant with wide gaps over a narrow mixture: columns never interleave
+                    base, ramp = (-6.0, 0.01) if si == 0 else ((0.0, 1.1) if si == 1 else (-9.0 - si, 0.003))
+                elif kind == 2:    # comparable sizes: everything interleaves
+                    base, ramp = -2.0 + 0.1 * si, 0.35
+                else:              # steep tails: the top rows peel off, the bottom ones interleave
+                    base, ramp = -3.0 + 0.05 * si, 0.0
+                vals = base + ramp * g + (0.0 if kind != 3 else 0.02 * g + 0.9 * np.maximum(g - 4.0, 0.0) ** 1.5)
+                a[bi] = col_scale - 2.0 + smooth[:, :, None] + vals[None, None, :]
+            if not sorted_k:
+                for k in tb.ktables:
+                    k["log10k"][bi] = k["log10k"][bi][..., ::-1] if bi % 2 else np.roll(k["log10k"][bi], 3, axis=-1)
+        r, o = _pair(O, tb, nz, 2, 0.2)
+        r.coop_items = 0          # the lane-per-item tile (the assembly block) whatever the item count
+        _compare_once(r, o, S.modern_earth_column(nz))

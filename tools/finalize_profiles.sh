@@ -1,11 +1,11 @@
 #!/bin/bash
-# After `gpurun -- 'bash tools/gpu_final.sh r03'`: condense gpurun_out/r03_* into profiles/ (run here).  ONE run,
+# After `gpurun -- 'bash tools/gpu_final.sh r04'`: condense gpurun_out/r04_* into profiles/ (run here).  ONE run,
 # ONE profiles commit at the end of the round.
-tag=${1:-r03}
-python3 tools/pmc_summary.py ${tag}_pmc profiles/${tag}_pmc_summary.md "PMC passes, round 3 final kernels (config 2: nz=200, nw=1000, ng=8, nzen=8)" --json profiles/${tag}_pmc.json config2_nz200_nzen8 | tail -1
+tag=${1:-r04}
+python3 tools/pmc_summary.py ${tag}_pmc profiles/${tag}_pmc_summary.md "PMC passes, round 4 final kernels (config 2: nz=200, nw=1000, ng=8, nzen=8)" --json profiles/${tag}_pmc.json config2_nz200_nzen8 | tail -1
 cp gpurun_out/${tag}_stats/run_kernel_stats.csv profiles/${tag}_kernel_stats_bench_steps100.csv
 for f in gpurun_out/${tag}_bench_line_*.json gpurun_out/${tag}_doubled_grid.txt gpurun_out/${tag}_adiabat_like.txt gpurun_out/${tag}_nz_sweep.txt \
-         gpurun_out/${tag}_ng_sweep.txt gpurun_out/${tag}_ir_batch.txt gpurun_out/${tag}_fortran_host.txt gpurun_out/${tag}_fortran_like.txt gpurun_out/${tag}_graph_ab.txt gpurun_out/${tag}_stamps.txt gpurun_out/${tag}_timeline.txt; do
+         gpurun_out/${tag}_ng_sweep.txt gpurun_out/${tag}_ir_batch.txt gpurun_out/${tag}_fortran_host.txt gpurun_out/${tag}_fortran_like.txt gpurun_out/${tag}_graph_ab.txt gpurun_out/${tag}_stamps.txt gpurun_out/${tag}_timeline.txt gpurun_out/${tag}_bench_line_gpus2_refused.txt; do
   [ -s "$f" ] && grep -v "amdgpu.ids" "$f" > profiles/$(basename "$f")
 done
 ls profiles | grep "^${tag}_"

@@ -450,8 +450,9 @@ def build():
 def main():
     global DEBUG
     emit(False, "rorr_xys_asm.inc", "RORR_XYS_ASM")
-    DEBUG = True
-    emit(True, "rorr_xys_asm_dbg.inc", "RORR_XYS_ASM_DBG")
+    if os.environ.get("CLIMA_RORR_DEBUG") == "1":   # (a variant with s_memtime samples at the phase boundaries: not used by any build)
+        DEBUG = True
+        emit(True, "rorr_xys_asm_dbg.inc", "RORR_XYS_ASM_DBG")
 
 
 def emit(dbg, fname, macro):

@@ -48,16 +48,3 @@ print("start histogram:", list(zip(np.round(edges[:-1], 1), hist)))
 late = st > 5
 print("late starters: %d, their life p50 %.1f us; early life p50 %.1f us" % (late.sum(), np.median((en - st)[late]) if late.any() else 0, np.median((en - st)[~late])))
 
-# the assembly form of the mixing step (rorr_xys_asm_dbg.inc): its own samples for the first wave of every 50th tile
-rec = np.array(s[7000:7000 + 16 * 4 * 8]).reshape(-1, 8)
-rec = rec[rec[:, 7] == 1]
-if len(rec):
-    d = (rec[:, 1:5] - rec[:, 0:4]) & 0xffffffff
-    print("assembly mixing steps sampled: %d; ticks: test + keys p50 %d, sort p50 %d, rebin p50 %d, coefficients p50 %d, whole p50 %d (min %d max %d)" % (
-        len(rec), np.median(d[:, 0]), np.median(d[:, 1]), np.median(d[:, 2]), np.median(d[:, 3]), np.median(d.sum(axis=1)), d.sum(axis=1).min(), d.sum(axis=1).max()))
-    for rows in sorted(set(rec[:, 5].tolist())):
-        m = rec[:, 5] == rows
-        dd = d[m]
-        print("   rows %d: %3d steps; test + keys %5d  sort %5d  rebin %5d  coefficients %5d  whole %6d;  merge masks %s" % (
-            rows, m.sum(), np.median(dd[:, 0]), np.median(dd[:, 1]), np.median(dd[:, 2]), np.median(dd[:, 3]), np.median(dd.sum(axis=1)),
-            sorted(set(bin(int(v)) for v in rec[m, 6]))[:6]))
