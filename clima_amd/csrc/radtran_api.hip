@@ -2202,7 +2202,9 @@ void radtran_comm_init_file(void *ptr, const int *nranks, const int *rank, const
   } else {
     bool got = false, stale = false;
     const time_t t_enter = time(nullptr);
-    for (int tries = 0; tries < 6000 && !got; tries++) {   // up to ~120 s
+    int max_tries = 6000;   // up to ~120 s (CLIMA_COMM_WAIT_S: another bound, in seconds -- the tests use 1)
+    if (const char *w = getenv("CLIMA_COMM_WAIT_S")) max_tries = std::max(1, atoi(w) * 50);
+    for (int tries = 0; tries < max_tries && !got; tries++) {
       struct stat st;
       if (stat(file.c_str(), &st) == 0 && st.st_size == (off_t)sizeof(rec)) {
         Record got_rec;

@@ -246,3 +246,22 @@ def test_ir_batch_on_communicator_handles(hip_lib, small_tables, mode):
     from clima_amd.radtran import ClimaException
     with pytest.raises(ClimaException, match="bin-sharded"):
         plain.radiate_ir_batch(Ts, T)
+
+
+def test_comm_init_file_refuses_another_jobs_record(tmp_path, monkeypatch):
+    """radtran_comm_init_file, a rank other than 0: a record at the path whose nonce (CLIMA_COMM_NONCE) or communicator size
+    is not this job's -- the leftover of a crashed or re-launched job -- is not joined (ncclCommInitRank on a dead id would
+    block for ever): the call returns an error once its wait is over."""
+    import struct
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import ClimaException, Radtran
+    r = Radtran(S.modern_earth_tables(nw=20), 30, 2, 0.2)
+    path = str(tmp_path / "id.bin")
+    # a well-formed record of ANOTHER job: magic, nranks = 2, nonce "old-job", 128 id bytes
+    with open(path, "wb") as f:
+        f.write(b"CLRCOMM1" + struct.pack("<i", 2) + b"old-job".ljust(64, b"\0") + bytes(128))
+    monkeypatch.setenv("CLIMA_COMM_NONCE", "this-job")
+    monkeypatch.setenv("CLIMA_COMM_WAIT_S", "1")
+    with pytest.raises(ClimaException, match="a record of another job"):
+        r.comm_init_file(2, 1, path)
+    assert r.comm() == (0, 0, 0) or r.comm()[0] == 0
