@@ -198,7 +198,9 @@ struct Radtran {
   // results
   DevBuf<double> d_small;     // flux_n[4*(nz+1)] | f_total[nz+1] | err flag slot: one D2H copy per call
   DevBuf<double> d_flux_n, d_f_total;   // views into d_small
-  std::vector<std::pair<void *, size_t>> host_registered;   // caller arrays page-locked by radtran_spectra_get_all
+  std::vector<std::pair<void *, size_t>> host_registered;   // caller arrays page-locked by radtran_spectra_get_all / radtran_radiate_ir_batch
+  double *batch_out[3] = {nullptr, nullptr, nullptr};       // the result arrays of the last radtran_radiate_ir_batch call
+  size_t batch_out_n = 0;
   hipStream_t copy_streams[3] = {nullptr, nullptr, nullptr}; // radtran_spectra_get_all: the seven copies go out over four queues
   double *h_small = nullptr;  // pinned: flux_n[4*(nz+1)] | f_total[nz+1] | err flag (as double slot)
   double *h_small_dev = nullptr;   // the same block as the device addresses it (null: not mapped)
@@ -1647,13 +1649,13 @@ static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, con
   ir_batch_general(r, d_T, d_Ts, ngen, r->d_gen_out.p, (size_t)ngen * nl);
   // 3. work arrays
   const size_t RQ = (size_t)N * NQ, LQ = (size_t)nl * NQ;
-  const int waves = ((ndev + 63) / 64) * ((nl + 15) / 16);    // of the far-form accumulation, per bin split
-  // bin splits: the accumulation's waves should fill the machine ONCE (1024 SIMDs x 3 waves of 152 registers): a few
-  // waves more than that and the kernel takes two rounds
-  const int qsplit = std::max(1, std::min(std::min(n_ir, 64), 2900 / std::max(waves, 1)));
+  const int waves = green_far_waves(ndev, nl);    // of the far-form accumulation, per bin split
+  // bin splits: the accumulation's waves should fill the machine ONCE (green_far_resident_waves): a few waves more
+  // than that and the kernel takes two rounds
+  const int qsplit = green_far_splits(n_ir, waves);
   const size_t FQ = (size_t)2 * ((nl + 15) / 16) * 34 * NQ;    // (GREEN_LB, GREEN_FS of ir_green.inc)
   const int msplit = std::max(qsplit, std::min(n_ir, 4096 / std::max((nmix + 3) / 4, 1)));   // the mixed blocks: few pairs, finer splits
-  const size_t total = 7 * RQ + 6 * LQ + FQ + 10 * LQ + (size_t)n_ir * ndev_pad + (size_t)(qsplit + msplit) * ndev_pad * 2 * nl;
+  const size_t total = 7 * RQ + 6 * LQ + FQ + 10 * LQ + (size_t)n_ir * ndev_pad + 64 + (size_t)(qsplit + msplit) * ndev_pad * 2 * nl;
   ensure(r->d_green, total);
   GreenParams g;
   std::memset(&g, 0, sizeof(g));
@@ -1665,7 +1667,7 @@ static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, con
   auto take = [&](size_t cnt) { double *p0 = w; w += cnt; return p0; };
   g.RW = take(7 * RQ);
   g.IS = take(6 * LQ); g.FS = take(FQ); g.DS = take(10 * LQ);
-  g.DB = take((size_t)n_ir * ndev_pad); g.partial = take((size_t)qsplit * ndev_pad * 2 * nl);
+  g.DB = take((size_t)n_ir * ndev_pad + 64); g.partial = take((size_t)qsplit * ndev_pad * 2 * nl);
   g.msplit = msplit; g.partial_m = take((size_t)msplit * ndev_pad * 2 * nl);
   g.ndev = ndev; g.ndev_pad = ndev_pad; g.qsplit = qsplit;
   g.dev_k = r->d_green_idx.p; g.col_src = g.dev_k + ndev_pad; g.col_ptr = g.col_src + n; g.col_dev = g.col_ptr + n + 1;
@@ -1679,6 +1681,8 @@ static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, con
   r->ir_green_batches++;
 }
 
+static void register_host(Radtran *r, void *p, size_t bytes);
+static bool host_is_registered(const Radtran *r, const void *p, size_t bytes);
 void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
                               const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
                               double *f_total, char *err) {
@@ -1689,6 +1693,10 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   if (!r->opr_valid) { set_err(err, "radiate_ir_batch needs opacities: call radiate with compute_opacity first"); return; }
   if (r->shard_world != 1 && !r->comm) { set_err(err, "radiate_ir_batch is not available on a bin-sharded handle"); return; }
   TRY
+  // CLIMA_HIP_BATCH_TIMES=1: the call's host-side phases on stderr (a diagnostic: tools/gpu_ir_batch.py)
+  static const bool times = [] { const char *e = getenv("CLIMA_HIP_BATCH_TIMES"); return e && e[0] == '1'; }();
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
   settle(r);          // (a communicator handle: the level rows of the last step are the reduced ones from here on)
   upload_fields(r);
   ensure_w0(r);
@@ -1746,11 +1754,35 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     HIPCHK(hipHostMalloc((void **)&r->h_bout, sizeof(double) * 3 * arr, hipHostMallocDefault));
     r->h_bout_n = 3 * arr;
   }
-  HIPCHK(hipMemcpyAsync(r->h_bout, r->d_bout.p, sizeof(double) * 3 * arr, hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
-  std::memcpy(fup_n, r->h_bout, sizeof(double) * arr);
-  std::memcpy(fdn_n, r->h_bout + arr, sizeof(double) * arr);
-  std::memcpy(f_total, r->h_bout + 2 * arr, sizeof(double) * arr);
+  const double t_enq = times ? since() : 0.0;
+  if (times) HIPCHK(hipStreamSynchronize(r->stream));
+  const double t_kern = times ? since() : 0.0;
+  // A caller that hands in the SAME three result arrays as in its last batch keeps them (the RCE solver's Jacobian
+  // does: src/adiabat/clima_adiabat_solve.f90:768-822 fills one work array per iteration): from the second such call on
+  // they are page-locked (as radtran_spectra_get_all does with the spectra; undone by radtran_spectra_release or with
+  // the handle) and the copies land in them directly -- at 403 columns x 403 levels the copy out of the pinned block took
+  // 140 of the call's 1080 us.
+  double *outs[3] = {fup_n, fdn_n, f_total};
+  const bool same = r->batch_out_n == arr && r->batch_out[0] == fup_n && r->batch_out[1] == fdn_n && r->batch_out[2] == f_total;
+  r->batch_out[0] = fup_n; r->batch_out[1] = fdn_n; r->batch_out[2] = f_total; r->batch_out_n = arr;
+  bool direct = same;
+  if (same)
+    for (double *o : outs) { register_host(r, o, sizeof(double) * arr); direct = direct && host_is_registered(r, o, sizeof(double) * arr); }
+  double t_d2h = 0.0;
+  if (direct) {
+    for (int i = 0; i < 3; i++)
+      HIPCHK(hipMemcpyAsync(outs[i], r->d_bout.p + (size_t)i * arr, sizeof(double) * arr, hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    t_d2h = times ? since() : 0.0;
+  } else {
+    HIPCHK(hipMemcpyAsync(r->h_bout, r->d_bout.p, sizeof(double) * 3 * arr, hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    t_d2h = times ? since() : 0.0;
+    for (int i = 0; i < 3; i++) std::memcpy(outs[i], r->h_bout + (size_t)i * arr, sizeof(double) * arr);
+  }
+  if (times)
+    fprintf(stderr, "radiate_ir_batch: %d columns%s: plan + enqueue %.0f us, kernels done at %.0f, results in the pinned block at %.0f, in the caller's arrays at %.0f\n",
+            n, green ? " (response form)" : "", t_enq, t_kern, t_d2h, since());
   CATCH(err)
 }
 
@@ -2550,7 +2582,7 @@ void clima_test_ir_response(const int *nz_, const int *ng_, const double *tau, c
   for (int i = 0; i < ndev; i++) { order[i] = i; if (dev_k[i] < 0 || dev_k[i] > nz) throw HipFail{"clima_test_ir_response: bad level"}; }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dev_k[a] < dev_k[b]; });
   const int ndev_pad = std::max(16, (ndev + 15) / 16 * 16), nblk = (nl + 15) / 16;
-  std::vector<double> h_tau((size_t)ng * nz), h_w0((size_t)ng * nz), h_db(ndev_pad, 0.0);
+  std::vector<double> h_tau((size_t)ng * nz), h_w0((size_t)ng * nz), h_db(ndev_pad + 64, 0.0);
   for (int c = 0; c < ng; c++)
     for (int i = 0; i < nz; i++) { h_tau[(size_t)c * nz + i] = tau[i]; h_w0[(size_t)c * nz + i] = w0[i]; }
   std::vector<int> hi(ndev_pad, 0), mdev, mblk;
@@ -2594,6 +2626,10 @@ void clima_test_ir_response(const int *nz_, const int *ng_, const double *tau, c
     }
   CATCH(err)
 }
+
+// which form of the response form's far accumulation the process uses from here on: 0 the matrix-core kernel
+// (k_green_accum_far_mfma, the default), 1 the vector kernel (k_green_accum_far; CLIMA_HIP_GREEN_MFMA=0 selects it too)
+void clima_test_green_far_form_set(const int *vector_form) { green_vector_form_set(*vector_form); }
 
 // ---- reference-named getters / setters (clima/fortran/Radtran.f90) -------------------
 
@@ -2763,6 +2799,11 @@ static void register_host(Radtran *r, void *p, size_t bytes) {
   if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) r->host_registered.emplace_back(p, bytes);
   else (void)hipGetLastError();
 }
+static bool host_is_registered(const Radtran *r, const void *p, size_t bytes) {
+  for (auto &e : r->host_registered)
+    if (e.first == p && e.second >= bytes) return true;
+  return false;
+}
 void radtran_spectra_get_all(void *ptr, const bool *do_solar, const int *nlev, const int *nw_ir, const int *nw_sol,
                              double *ir_fup_a, double *ir_fdn_a, double *ir_tau_band,
                              double *sol_fup_a, double *sol_fdn_a, double *sol_amean, double *sol_tau_band, char *err) {
@@ -2801,6 +2842,7 @@ void radtran_spectra_release(void *ptr) {
   if (!r) return;
   for (auto &e : r->host_registered) (void)hipHostUnregister(e.first);
   r->host_registered.clear();
+  r->batch_out_n = 0;
 }
 
 // ---- ClimaRadtranWrk (clima/fortran/ClimaRadtranWrk.f90) ------------------------------

@@ -301,7 +301,7 @@ struct GreenParams {
   int ndev, ndev_pad;
   const int *dev_k;
   const double *dev_T, *base_T;            // base_T[k], k TOA-first, k = nz: surface
-  double *DB;                              // [n_ir][ndev_pad]
+  double *DB;                              // [n_ir][ndev_pad] + 64 doubles of slack (k_green_accum_far_mfma's tiles past the list)
   int qsplit;
   int nmix;                                // (deviation, level block) pairs of mixed class
   const int *mix_dev, *mix_blk;
@@ -319,6 +319,10 @@ void launch_green_factor(const GreenParams &p, hipStream_t s);
 void launch_green_columns(const GreenParams &p, int ncol, hipStream_t s);
 void launch_batch_ftotal(double *out, size_t out_arr, int ncol, int nz, const double *flux_n, hipStream_t s);
 void launch_green_accumulate(const GreenParams &p, hipStream_t s);   // the accumulation alone (test hook: DB given)
+int green_far_resident_waves();
+void green_vector_form_set(int vector_form);   // test hook: the far accumulation's vector form (1) or matrix form (0)
+int green_far_waves(int ndev, int nl);   // per bin split
+int green_far_splits(int n_ir, int waves);
 
 // launchers (kernels.hip)
 void launch_prep(const PrepParams &p, hipStream_t s);

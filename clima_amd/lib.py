@@ -89,6 +89,7 @@ SIGNATURES = {
     "clima_test_device_rcp": [_ip, _dp, _dp, _err],
     "clima_test_wave_scan": [_ip, _dp, _dp, _dp, _err],
     "clima_test_two_stream": [_ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],
+    "clima_test_green_far_form_set": [_ip],
     "clima_test_ir_response": [_ip, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _err],
     "radtran_set_bolometric_flux_wrapper": [_vp, _dp],
     "radtran_bolometric_flux_wrapper": [_vp, _dp],

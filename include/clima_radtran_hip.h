@@ -181,7 +181,10 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
  * call; the handle's own wrk_ir / f_total are left untouched.  On a handle with a communicator
  * (radtran_comm_init_rank) every rank passes the same columns, works on its share of the bins and the library
  * all-reduces the batch's up / down arrays once (2 (nz+1) ncol doubles) before f_total is formed: every rank
- * receives the whole result.  A bin shard without a communicator (radtran_set_bin_shard) is refused. */
+ * receives the whole result.  A bin shard without a communicator (radtran_set_bin_shard) is refused.
+ * A caller that passes the same three result arrays as in its previous batch call (the Jacobian's work arrays) has
+ * them page-locked from that second call on, like the arrays of radtran_spectra_get_all, and filled by the device
+ * directly: call radtran_spectra_release before freeing them. */
 void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
                               const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
                               double *f_total, char *err);
@@ -327,6 +330,10 @@ void clima_test_two_stream(const int *nz, const int *ng, const int *form, const 
 void clima_test_ir_response(const int *nz, const int *ng, const double *tau, const double *w0, const double *g,
                             const double *ir_par, const double *wbin, const int *ndev, const int *dev_k,
                             const double *dev_db, double *resp_up, double *resp_dn, char *err);
+
+/* The far accumulation of the response form has two kernels: 0 (default) the matrix-core one (v_mfma_f64_16x16x4_f64),
+ * 1 the vector one it replaced (also CLIMA_HIP_GREEN_MFMA=0).  Process-wide; tests hold the two against each other. */
+void clima_test_green_far_form_set(const int *vector_form);
 
 /* OpticalPropertiesResult (clima_radtran_types.f90:242-247), for parity checks:
  * tau,w0 (nz,ngauss,nw) and g,tau_band (nz,nw), column-major, TOA-first. */

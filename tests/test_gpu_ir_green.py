@@ -132,7 +132,7 @@ def test_response_form_is_chosen_by_itself_for_a_jacobian_sized_batch():
         assert _scaled(x, y) <= 1e-11
 
 
-@pytest.mark.parametrize("ng,nz", [(4, 50), (12, 70), (16, 130), (32, 40)])
+@pytest.mark.parametrize("ng,nz", [(4, 50), (6, 60), (12, 70), (16, 130), (32, 40)])
 def test_response_form_at_other_g_point_counts(O, ng, nz):
     from clima_amd import synthetic as S
     from test_gpu_parity import _pair
@@ -273,3 +273,35 @@ def test_response_form_with_steps_far_below_what_two_solves_can_resolve(O, small
             tol = 2e-6 + 500.0 * rs + 3e-15 / rs
             assert np.max(np.abs(have - want)) <= tol * np.max(np.abs(want)), (j, rs, np.max(np.abs(have - want)) / np.max(np.abs(want)))
             c += 1
+
+
+@pytest.mark.parametrize("nz,ncol,ng", [(202, 230, 8), (130, 150, 8), (70, 90, 6), (40, 50, 3)])
+def test_far_accumulation_on_the_matrix_cores_against_the_vector_kernel(nz, ncol, ng):
+    """k_green_accum_far_mfma (v_mfma_f64_16x16x4_f64: one wave = 64 consecutive deviations of a block pair's below-form
+    prefix or above-form suffix, four q per K step) against k_green_accum_far (vector FMAs, fixed groups of 64
+    deviations, both forms per group) on batches with several chunks per block, a last chunk that is not full, splits
+    whose q count is not a multiple of four (6 and 3 g-points) and an odd number of level blocks (40 and 70 layers: the last
+    pair has one block).  The two sum the same terms in different orders: rounding only."""
+    import ctypes as C
+    from clima_amd import synthetic as S
+    from clima_amd.lib import load
+    from clima_amd.radtran import Radtran
+    L = load()
+    tb = S.modern_earth_tables(nw=24, ng=ng, seed=7 + ng) if ng != 8 else S.modern_earth_tables(nw=40, seed=11)
+    col = S.modern_earth_column(nz)
+    r = Radtran(tb, nz, 2, 0.2)
+    r.radiate(*col.args())
+    rng = np.random.default_rng(nz + ncol)
+    Ts, T = _jacobian_batch(col, nz, ncol, rng)
+    r.ir_green = 2
+    res = {}
+    try:
+        for form in (1, 0):
+            L.clima_test_green_far_form_set(C.byref(C.c_int(form)))
+            res[form] = r.radiate_ir_batch(Ts, T)
+    finally:
+        L.clima_test_green_far_form_set(C.byref(C.c_int(0)))
+    assert r.ir_green_batches == 2
+    for a, b in zip(res[0], res[1]):
+        for c in range(ncol):
+            assert _scaled(a[:, c], b[:, c]) <= 2.0e-13, (c, _scaled(a[:, c], b[:, c]))

@@ -1,0 +1,5 @@
+set -o pipefail
+o=gpurun_out
+rm -rf $o/green_prof
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/green_prof -o run -- python3 tools/gpu_ir_batch.py 200 > $o/green_prof.log 2>&1; echo "rc $?"
+grep -i "green\|ir_batch" $o/green_prof/run_kernel_stats.csv | cut -c1-220
