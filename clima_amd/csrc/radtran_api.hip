@@ -155,7 +155,8 @@ struct Radtran {
   // batched shared-opacity IR calls (radtran_radiate_ir_batch)
   DevBuf<double> d_bT, d_bTs, d_bup, d_bdn, d_bpartial, d_bout;
   // ... and its response form (ir_green.inc): work arrays, deviation lists, the general sub-batch's rows
-  DevBuf<double> d_green, d_green_in, d_gen_out;
+  DevBuf<double> d_green, d_green_acc, d_green_in, d_gen_out;
+  int green_last_n = -1;           // columns of the last batch, when it took the response form (the next one of that size starts its opacity-only part early)
   double *h_bout = nullptr;        // pinned: the batch's three result arrays on their way to the caller's
   size_t h_bout_n = 0;
   char *h_green = nullptr;         // pinned: what the host hands the response form (base profile, deviation lists)
@@ -1594,9 +1595,37 @@ static void green_plan(const double *T, const double *Ts, int n, int nz, GreenPl
   for (size_t s2 = 0; s2 < order.size(); s2++) pl.col_dev[fill[dc[order[s2]]]++] = (int)s2;
 }
 
-static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, const double *Ts, int n, double *d_out) {
+// The part of the response form that sees the opacities alone (k_green_factor, k_green_unit, k_green_local: ~345 of the
+// ~700 us of GPU work of a 402-layer Jacobian batch): its arrays and launches.  radtran_radiate_ir_batch issues it BEFORE
+// the host looks at the columns when the handle's last batch of this size took the response form -- the plan (~100 us of
+// host time at 403 columns) then runs beside it instead of in front of it.
+// (Measured and not kept: a second queue for the kernels that do not depend on each other -- k_green_local beside
+// k_green_unit, the base profile's general kernel beside k_green_factor, the mixed blocks' sums beside the far-form
+// ones.  rocprofv3's kernel trace shows them side by side and each that much slower: the far-form kernel holds 2 x 232
+// registers per SIMD, the general kernel one wave of 512, and the batch took 828-840 us either way.)
+static void green_factor_part(Radtran *r, GreenParams &g) {
   const int nz = r->nz, nl = nz + 1, N = 2 * nz, ng = r->ng, n_ir = r->ir_n;
   const int NQ = n_ir * ng;
+  const size_t RQ = (size_t)N * NQ, LQ = (size_t)nl * NQ;
+  const size_t FQ = (size_t)2 * ((nl + 15) / 16) * 34 * NQ;    // (GREEN_LB, GREEN_FS of ir_green.inc)
+  const size_t total = 7 * RQ + 6 * LQ + FQ + 10 * LQ;
+  if (r->d_green.n < total) r->d_green.alloc(total);
+  std::memset(&g, 0, sizeof(g));
+  g.nz = nz; g.ng = ng; g.n_ir = n_ir; g.ir_lo = r->ir_lo; g.ir_start = r->ir.ind_start; g.NQ = NQ;
+  g.tau = r->d_tau.p; g.w0 = r->d_w0.p; g.g = r->d_g.p; g.wbin = r->d_wbin.p;
+  g.freq = r->d_freq.p; g.ir_freq = r->ir.d_freq.p; g.emissivity = r->d_emis.p;
+  g.has_hard_surface = r->has_hard_surface ? 1 : 0; g.ir_tau_min = r->ir_tau_min;
+  double *w = r->d_green.p;
+  auto take = [&](size_t cnt) { double *p0 = w; w += cnt; return p0; };
+  g.RW = take(7 * RQ);
+  g.IS = take(6 * LQ); g.FS = take(FQ); g.DS = take(10 * LQ);
+  launch_green_factor(g, r->stream);
+  HIPCHK(hipGetLastError());
+}
+
+// `pre`: the opacity-only part has been issued already (green_factor_part's parameter block)
+static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, const double *Ts, int n, double *d_out, const GreenParams *pre) {
+  const int nz = r->nz, nl = nz + 1, n_ir = r->ir_n;
   auto ensure = [](DevBuf<double> &b, size_t count) { if (b.n < count) b.alloc(count); };
   // 1. the base profile and the dense columns through the general kernel
   const int ngen = 1 + (int)pl.dense.size();
@@ -1647,26 +1676,18 @@ static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, con
   HIPCHK(hipMemcpyAsync(r->d_green_idx.p, hi, sizeof(int) * ni, hipMemcpyHostToDevice, r->stream));
   const double *d_T = r->d_green_in.p, *d_Ts = d_T + (size_t)ngen * nz;
   ir_batch_general(r, d_T, d_Ts, ngen, r->d_gen_out.p, (size_t)ngen * nl);
-  // 3. work arrays
-  const size_t RQ = (size_t)N * NQ, LQ = (size_t)nl * NQ;
+  // 3. the opacity-only part (unless it is under way already) and the accumulation's arrays
+  GreenParams g;
+  if (pre) g = *pre;
+  else green_factor_part(r, g);
   const int waves = green_far_waves(ndev, nl);    // of the far-form accumulation, per bin split
   // bin splits: the accumulation's waves should fill the machine ONCE (green_far_resident_waves): a few waves more
   // than that and the kernel takes two rounds
   const int qsplit = green_far_splits(n_ir, waves);
-  const size_t FQ = (size_t)2 * ((nl + 15) / 16) * 34 * NQ;    // (GREEN_LB, GREEN_FS of ir_green.inc)
   const int msplit = std::max(qsplit, std::min(n_ir, 4096 / std::max((nmix + 3) / 4, 1)));   // the mixed blocks: few pairs, finer splits
-  const size_t total = 7 * RQ + 6 * LQ + FQ + 10 * LQ + (size_t)n_ir * ndev_pad + 64 + (size_t)(qsplit + msplit) * ndev_pad * 2 * nl;
-  ensure(r->d_green, total);
-  GreenParams g;
-  std::memset(&g, 0, sizeof(g));
-  g.nz = nz; g.ng = ng; g.n_ir = n_ir; g.ir_lo = r->ir_lo; g.ir_start = r->ir.ind_start; g.NQ = NQ;
-  g.tau = r->d_tau.p; g.w0 = r->d_w0.p; g.g = r->d_g.p; g.wbin = r->d_wbin.p;
-  g.freq = r->d_freq.p; g.ir_freq = r->ir.d_freq.p; g.emissivity = r->d_emis.p;
-  g.has_hard_surface = r->has_hard_surface ? 1 : 0; g.ir_tau_min = r->ir_tau_min;
-  double *w = r->d_green.p;
+  ensure(r->d_green_acc, (size_t)n_ir * ndev_pad + 64 + (size_t)(qsplit + msplit) * ndev_pad * 2 * nl);
+  double *w = r->d_green_acc.p;
   auto take = [&](size_t cnt) { double *p0 = w; w += cnt; return p0; };
-  g.RW = take(7 * RQ);
-  g.IS = take(6 * LQ); g.FS = take(FQ); g.DS = take(10 * LQ);
   g.DB = take((size_t)n_ir * ndev_pad + 64); g.partial = take((size_t)qsplit * ndev_pad * 2 * nl);
   g.msplit = msplit; g.partial_m = take((size_t)msplit * ndev_pad * 2 * nl);
   g.ndev = ndev; g.ndev_pad = ndev_pad; g.qsplit = qsplit;
@@ -1674,8 +1695,6 @@ static void ir_batch_green(Radtran *r, const GreenPlan &pl, const double *T, con
   g.nmix = nmix; g.mix_dev = g.col_dev + ndev; g.mix_blk = g.mix_dev + nmix;
   g.dev_T = d_Ts + ngen; g.base_T = g.dev_T + ndev_pad;
   g.gen_out = r->d_gen_out.p; g.gen_arr = (size_t)ngen * nl; g.flux_n = r->d_flux_n.p; g.out = d_out; g.out_arr = (size_t)n * nl;
-  launch_green_factor(g, r->stream);
-  HIPCHK(hipGetLastError());
   launch_green_columns(g, n, r->stream);
   HIPCHK(hipGetLastError());
   r->ir_green_batches++;
@@ -1705,6 +1724,11 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   ensure(r->d_bout, (size_t)n * 3 * nl);
   bool green = false;
   if (r->ir_green_mode != 0 && r->batch_shared && nz >= 4 && nz <= 512 && r->ir_n > 0) {   // (CLIMA_HIP_BATCH_SHARED=0: one full solve per column, bit for bit the single call)
+    // k_green_unit / k_green_local take one (bin, g-point) pair per blockIdx.y: a grid dimension of at most 65535
+    const bool fits = (long)r->ir_n * r->ng <= 65535;
+    GreenParams gpre;
+    bool pre = false;
+    if (fits && r->green_last_n == n) { green_factor_part(r, gpre); pre = true; }
     GreenPlan pl;
     green_plan(T, T_surface, n, nz, pl);
     // worth it from a few dozen sparse columns of a tall grid on (measured: 203 columns x 202 layers 0.60 against 1.29 ms,
@@ -1719,7 +1743,7 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
       // pass + the accumulation over deviations x levels + the extra launches
       const double scale = (double)r->ir_n * r->ng / 4800.0;
       const double t_general = pl.n_sparse * (nz <= 256 ? 0.032e-3 : 0.044e-3) * nz * scale;
-      const double t_green = 0.05 + scale * (0.35 * nz / 402.0 + 0.56 * (double)pl.dev_k.size() * nl / 162409.0);
+      const double t_green = 0.05 + scale * (0.35 * nz / 402.0 + 0.28 * (double)pl.dev_k.size() * nl / 162409.0);   // (round 4: the accumulation on the matrix cores)
       green = t_green < 0.8 * t_general;
     }
     // not with a base that is not a number anywhere (every column would "deviate" there and inherit it), nor when the
@@ -1728,9 +1752,9 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     // (the partial sums of the two accumulation kernels are part of that: at most (64 + bins) splits x deviations x 2 x levels)
     if (((double)r->ir_n * r->ng * (13.0 * nl + 14.0 * nz + 4.3 * nl) +
          (64.0 + r->ir_n) * ((double)pl.dev_k.size() + 64.0) * 2.0 * nl) * 8.0 > 16.0e9) green = false;
-    // k_green_unit / k_green_local take one (bin, g-point) pair per blockIdx.y: a grid dimension of at most 65535
-    if ((long)r->ir_n * r->ng > 65535) green = false;
-    if (green) ir_batch_green(r, pl, T, T_surface, n, r->d_bout.p);
+    if (!fits) green = false;
+    if (green) ir_batch_green(r, pl, T, T_surface, n, r->d_bout.p, pre ? &gpre : nullptr);
+    r->green_last_n = green ? n : -1;
   }
   if (!green) {
     ensure(r->d_bT, (size_t)n * nz); ensure(r->d_bTs, n);
