@@ -3555,9 +3555,20 @@ __global__ __launch_bounds__(256) void k_integrate_partial_b(BatchIntegrateParam
   const double *src = (a == 0 ? p.fup_a : p.fdn_a) + (size_t)col * p.spec_stride;
   const int l0 = p.ir_lo + blockIdx.x * INT_CHUNK;
   const int l1 = min(p.ir_lo + p.ir_n, l0 + INT_CHUNK);
+  // (the chunk's loads go out together: one after the other, each waiting for the one before, a one-column batch -- the
+  // response form's base profile -- spent 18 us here)
   for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+    double v[INT_CHUNK], df[INT_CHUNK];
+#pragma unroll
+    for (int k = 0; k < INT_CHUNK; k++) {
+      const int l = min(l0 + k, l1 - 1);
+      v[k] = src[(size_t)l * nl + i];
+      df[k] = p.freq[l] - p.freq[l + 1];
+    }
     double acc = 0.0;
-    for (int l = l0; l < l1; l++) acc = __builtin_fma(src[(size_t)l * nl + i], p.freq[l] - p.freq[l + 1], acc);
+#pragma unroll
+    for (int k = 0; k < INT_CHUNK; k++)
+      if (l0 + k < l1) acc = __builtin_fma(v[k], df[k], acc);
     p.partial[(((size_t)col * 2 + a) * p.nchunk + blockIdx.x) * nl + i] = acc;
   }
 }
@@ -3567,9 +3578,17 @@ __global__ __launch_bounds__(256) void k_integrate_final_b(BatchIntegrateParams 
   const int col = blockIdx.x;
   for (int i = threadIdx.x; i < nl; i += blockDim.x) {
     double up = 0.0, dn = 0.0;
-    for (int k = 0; k < p.nchunk; k++) {
-      up = up + p.partial[(((size_t)col * 2 + 0) * p.nchunk + k) * nl + i];
-      dn = dn + p.partial[(((size_t)col * 2 + 1) * p.nchunk + k) * nl + i];
+    for (int k0 = 0; k0 < p.nchunk; k0 += 8) {      // (eight chunk sums of each array in flight, added in chunk order)
+      double u[8], d[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int kk = min(k0 + k, p.nchunk - 1);
+        u[k] = p.partial[(((size_t)col * 2 + 0) * p.nchunk + kk) * nl + i];
+        d[k] = p.partial[(((size_t)col * 2 + 1) * p.nchunk + kk) * nl + i];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (k0 + k < p.nchunk) { up = up + u[k]; dn = dn + d[k]; }
     }
     double *o = p.out + (size_t)(p.col0 + col) * nl;
     o[i] = up;

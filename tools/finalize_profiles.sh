@@ -8,4 +8,6 @@ for f in gpurun_out/${tag}_bench_line_*.json gpurun_out/${tag}_doubled_grid.txt 
          gpurun_out/${tag}_ng_sweep.txt gpurun_out/${tag}_ir_batch.txt gpurun_out/${tag}_fortran_host.txt gpurun_out/${tag}_fortran_like.txt gpurun_out/${tag}_graph_ab.txt gpurun_out/${tag}_stamps.txt gpurun_out/${tag}_timeline.txt gpurun_out/${tag}_bench_line_gpus2_refused.txt; do
   [ -s "$f" ] && grep -v "amdgpu.ids" "$f" > profiles/$(basename "$f")
 done
+[ -s gpurun_out/${tag}_green_stats/run_kernel_stats.csv ] && grep -i "green\|ir_batch\|Name" gpurun_out/${tag}_green_stats/run_kernel_stats.csv > profiles/${tag}_green_kernel_stats.csv
+for f in gpurun_out/${tag}_green_timeline.txt gpurun_out/${tag}_green_pmc.txt; do [ -s "$f" ] && cp "$f" profiles/; done
 ls profiles | grep "^${tag}_"

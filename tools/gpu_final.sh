@@ -42,6 +42,7 @@ fi
 if want sweeps2; then
 run ng_sweep.txt python3 tools/gpu_ng_sweep.py || exit 1
 run ir_batch.txt python3 tools/gpu_ir_batch.py 50 100 200 249 || exit 1
+bash tools/gpu_green_profile.sh $tag || exit 1                           # the response form's kernels under rocprofv3 (stats, timeline, PMC)
 run fortran_host.txt python3 tools/gpu_fortran_host.py || exit 1      # the drop-in call timed by a Fortran host
 run fortran_like.txt python3 tools/gpu_fortran_like.py || exit 1      # ... and what pushing the public fields before every call costs
 run graph_ab.txt python3 tools/gpu_graph_ab.py || exit 1              # a hipGraph replay of the call's launches beside the plain launches
