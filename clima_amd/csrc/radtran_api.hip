@@ -202,6 +202,8 @@ struct Radtran {
   std::vector<std::pair<void *, size_t>> host_registered;   // caller arrays page-locked by radtran_spectra_get_all / radtran_radiate_ir_batch
   double *batch_out[3] = {nullptr, nullptr, nullptr};       // the result arrays of the last radtran_radiate_ir_batch call
   size_t batch_out_n = 0;
+  bool batch_pin_results = false;                           // radtran_batch_pin_results_set
+  hipEvent_t bout_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the batch's result pieces
   hipStream_t copy_streams[3] = {nullptr, nullptr, nullptr}; // radtran_spectra_get_all: the seven copies go out over four queues
   double *h_small = nullptr;  // pinned: flux_n[4*(nz+1)] | f_total[nz+1] | err flag (as double slot)
   double *h_small_dev = nullptr;   // the same block as the device addresses it (null: not mapped)
@@ -259,6 +261,7 @@ struct Radtran {
     if (h_col) (void)hipHostFree(h_col);
     for (auto &e : host_registered) (void)hipHostUnregister(e.first);
     for (auto &cs : copy_streams) if (cs) (void)hipStreamDestroy(cs);
+    for (auto &e : bout_ev) if (e) (void)hipEventDestroy(e);
     if (h_small) (void)hipHostFree(h_small);
     if (h_bout) (void)hipHostFree(h_bout);
     if (h_green) (void)hipHostFree(h_green);
@@ -1781,17 +1784,21 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   const double t_enq = times ? since() : 0.0;
   if (times) HIPCHK(hipStreamSynchronize(r->stream));
   const double t_kern = times ? since() : 0.0;
-  // A caller that hands in the SAME three result arrays as in its last batch keeps them (the RCE solver's Jacobian
-  // does: src/adiabat/clima_adiabat_solve.f90:768-822 fills one work array per iteration): from the second such call on
-  // they are page-locked (as radtran_spectra_get_all does with the spectra; undone by radtran_spectra_release or with
-  // the handle) and the copies land in them directly -- at 403 columns x 403 levels the copy out of the pinned block took
-  // 140 of the call's 1080 us.
+  // The three result arrays (3.9 MB at 403 columns x 403 levels).  Default: through the handle's pinned block in pieces,
+  // the host copying piece i into the caller's arrays while piece i + 1 is still on the link (one copy and then one
+  // memcpy of the whole took 95 + 140 us of a 0.93 ms call).  radtran_batch_pin_results_set(1): the caller's arrays are
+  // page-locked when it passes the same three as in its previous batch (the Jacobian's work arrays: the RCE solver fills
+  // one set per iteration, src/adiabat/clima_adiabat_solve.f90:768-822) and the device fills them directly -- opt-in,
+  // because the arrays must then stay allocated until radtran_spectra_release or the handle's end.
   double *outs[3] = {fup_n, fdn_n, f_total};
-  const bool same = r->batch_out_n == arr && r->batch_out[0] == fup_n && r->batch_out[1] == fdn_n && r->batch_out[2] == f_total;
-  r->batch_out[0] = fup_n; r->batch_out[1] = fdn_n; r->batch_out[2] = f_total; r->batch_out_n = arr;
-  bool direct = same;
-  if (same)
-    for (double *o : outs) { register_host(r, o, sizeof(double) * arr); direct = direct && host_is_registered(r, o, sizeof(double) * arr); }
+  bool direct = false;
+  if (r->batch_pin_results) {
+    const bool same = r->batch_out_n == arr && r->batch_out[0] == fup_n && r->batch_out[1] == fdn_n && r->batch_out[2] == f_total;
+    r->batch_out[0] = fup_n; r->batch_out[1] = fdn_n; r->batch_out[2] = f_total; r->batch_out_n = arr;
+    direct = same;
+    if (same)
+      for (double *o : outs) { register_host(r, o, sizeof(double) * arr); direct = direct && host_is_registered(r, o, sizeof(double) * arr); }
+  }
   double t_d2h = 0.0;
   if (direct) {
     for (int i = 0; i < 3; i++)
@@ -1799,14 +1806,29 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     HIPCHK(hipStreamSynchronize(r->stream));
     t_d2h = times ? since() : 0.0;
   } else {
-    HIPCHK(hipMemcpyAsync(r->h_bout, r->d_bout.p, sizeof(double) * 3 * arr, hipMemcpyDeviceToHost, r->stream));
-    HIPCHK(hipStreamSynchronize(r->stream));
+    constexpr int NPIECE = 6;
+    const size_t total = 3 * arr, piece = (total + NPIECE - 1) / NPIECE;
+    for (auto &e : r->bout_ev)
+      if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (int k = 0; k < NPIECE; k++) {
+      const size_t lo = std::min(total, (size_t)k * piece), hi = std::min(total, lo + piece);
+      if (hi > lo) HIPCHK(hipMemcpyAsync(r->h_bout + lo, r->d_bout.p + lo, sizeof(double) * (hi - lo), hipMemcpyDeviceToHost, r->stream));
+      HIPCHK(hipEventRecord(r->bout_ev[k], r->stream));
+    }
+    for (int k = 0; k < NPIECE; k++) {
+      const size_t lo = std::min(total, (size_t)k * piece), hi = std::min(total, lo + piece);
+      HIPCHK(hipEventSynchronize(r->bout_ev[k]));
+      for (size_t x = lo; x < hi;) {      // (a piece may straddle two of the three arrays)
+        const size_t i = x / arr, n_here = std::min(hi, (i + 1) * arr) - x;
+        std::memcpy(outs[i] + (x - i * arr), r->h_bout + x, sizeof(double) * n_here);
+        x += n_here;
+      }
+    }
     t_d2h = times ? since() : 0.0;
-    for (int i = 0; i < 3; i++) std::memcpy(outs[i], r->h_bout + (size_t)i * arr, sizeof(double) * arr);
   }
   if (times)
-    fprintf(stderr, "radiate_ir_batch: %d columns%s: plan + enqueue %.0f us, kernels done at %.0f, results in the pinned block at %.0f, in the caller's arrays at %.0f\n",
-            n, green ? " (response form)" : "", t_enq, t_kern, t_d2h, since());
+    fprintf(stderr, "radiate_ir_batch: %d columns%s: plan + enqueue %.0f us, kernels done at %.0f, results with the caller at %.0f%s\n",
+            n, green ? " (response form)" : "", t_enq, t_kern, t_d2h, direct ? " (its arrays page-locked)" : " (through the pinned block, six pieces)");
   CATCH(err)
 }
 
@@ -2860,6 +2882,14 @@ void radtran_spectra_get_all(void *ptr, const bool *do_solar, const int *nlev, c
   }
   for (int k = 0; k < 4; k++) HIPCHK(hipStreamSynchronize(qs[k]));
   CATCH(err)
+}
+void radtran_batch_pin_results_set(void *ptr, const int *flag) {
+  Radtran *r = as_rad(ptr);
+  if (r && r->batch_pin_results != (*flag != 0)) { r->batch_pin_results = *flag != 0; r->batch_out_n = 0; }
+}
+void radtran_batch_pin_results_get(void *ptr, int *flag) {
+  Radtran *r = as_rad(ptr);
+  *flag = r && r->batch_pin_results ? 1 : 0;
 }
 void radtran_spectra_release(void *ptr) {
   Radtran *r = as_rad(ptr);

@@ -59,6 +59,10 @@ module clima_radtran_hip
     !> copy the per-bin spectra (fup_a, fdn_a, amean, tau_band) back after every radiate;
     !> set to .false. when only the level fluxes are needed (saves ~7 MB of PCIe per call)
     logical :: sync_spectra = .true.
+    !> radiate_ir_batch: page-lock the three result arrays when the same ones come again (the Jacobian's work arrays) and
+    !> let the device fill them directly (include/clima_radtran_hip.h, radtran_batch_pin_results_set).  The arrays must then
+    !> stay allocated until `destroy`.  Off by default.
+    logical :: pin_batch_results = .false.
     type(c_ptr) :: handle = c_null_ptr
   contains
     procedure :: begin => Radtran_begin
@@ -91,6 +95,7 @@ module clima_radtran_hip
     procedure :: comm_init_file => Radtran_comm_init_file
     procedure :: comm_destroy => Radtran_comm_destroy
     procedure :: set_ir_green => Radtran_set_ir_green
+    procedure :: release_pinned => Radtran_release_pinned
     procedure :: ir_green_batches => Radtran_ir_green_batches
   end type
 
@@ -384,6 +389,10 @@ module clima_radtran_hip
     end subroutine
     subroutine c_radtran_comm_destroy(ptr) bind(c, name="radtran_comm_destroy")
       import; type(c_ptr), value :: ptr
+    end subroutine
+    subroutine c_radtran_batch_pin_results_set(ptr, flag) bind(c, name="radtran_batch_pin_results_set")
+      import; type(c_ptr), value :: ptr
+      integer(c_int), intent(in) :: flag
     end subroutine
     subroutine c_radtran_ir_green_set(ptr, mode) bind(c, name="radtran_ir_green_set")
       import; type(c_ptr), value :: ptr
@@ -789,6 +798,7 @@ contains
       err = '"T" has the wrong input dimension.'
       return
     endif
+    call c_radtran_batch_pin_results_set(self%handle, merge(1_c_int, 0_c_int, self%pin_batch_results))
     call c_radtran_radiate_ir_batch(self%handle, ncol, T_surface, size(T,1), size(T,2), T, fup_n, fdn_n, f_total, err_c)
     call take_err(err_c, err)
   end subroutine
@@ -927,6 +937,13 @@ contains
   !> `radiate_ir_batch`'s response form (include/clima_radtran_hip.h, radtran_ir_green_set): 0 never, 1 (default) when
   !> the batch is large and its columns are one profile with a few temperatures changed each -- what
   !> AdiabatClimate_jacobian_from_base (src/adiabat/clima_adiabat_solve.f90:768-822) issues --, 2 whenever any column is.
+  !> un-page-lock the caller arrays the library locked (`sync_spectra`'s seven, `pin_batch_results`' three): before they
+  !> are deallocated while the object lives on (`destroy` does it too)
+  subroutine Radtran_release_pinned(self)
+    class(Radtran), intent(inout) :: self
+    if (c_associated(self%handle)) call c_radtran_spectra_release(self%handle)
+  end subroutine
+
   subroutine Radtran_set_ir_green(self, mode)
     class(Radtran), intent(inout) :: self
     integer, intent(in) :: mode

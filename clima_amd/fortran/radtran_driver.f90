@@ -245,6 +245,7 @@ contains
     Tb(:,1) = T
     call system_clock(count_rate=rate)
     rad%sync_spectra = .false.
+    rad%pin_batch_results = .true.     ! (bup, bdn, bft live until the end of this routine: released below)
     do mode = 0, 1
       call rad%set_ir_green(mode)
       best(mode+1) = huge(1.0_dp)
@@ -272,6 +273,8 @@ contains
       ' layers: rad%radiate_ir_batch ', best(2), ' ms (general kernel ', best(1), ' ms), one rad%radiate at a time ', t_loop, &
       ' ms; largest difference between the two batch forms ', maxval(abs(bft - gft))/maxval(abs(gft)), &
       ' of the maximum; batches in the response form: ', rad%ir_green_batches()
+    rad%pin_batch_results = .false.
+    call rad%release_pinned()
   end subroutine
 
   subroutine time_calls()

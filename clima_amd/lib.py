@@ -90,6 +90,8 @@ SIGNATURES = {
     "clima_test_wave_scan": [_ip, _dp, _dp, _dp, _err],
     "clima_test_two_stream": [_ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _err],
     "clima_test_green_far_form_set": [_ip],
+    "radtran_batch_pin_results_set": [_vp, _ip],
+    "radtran_batch_pin_results_get": [_vp, _ip],
     "clima_test_ir_response": [_ip, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _err],
     "radtran_set_bolometric_flux_wrapper": [_vp, _dp],
     "radtran_bolometric_flux_wrapper": [_vp, _dp],

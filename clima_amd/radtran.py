@@ -329,18 +329,25 @@ class Radtran:
             return isr, olr, np.transpose(fl, (2, 1, 0))
         return isr, olr
 
-    def radiate_ir_batch(self, T_surface, T, out=None):
+    def radiate_ir_batch(self, T_surface, T, out=None, pin=False):
         """ncol IR-only calls with the resident opacities in one go: column c is
         `radiate(T_surface[c], T[:, c], ..., compute_solar=False, compute_opacity=False)`
         (the RCE Jacobian's loop, src/adiabat/clima_adiabat_solve.f90:798-812).
-        Returns (fup_n, fdn_n, f_total), each (nz+1, ncol)."""
+        Returns (fup_n, fdn_n, f_total), each (nz+1, ncol).  `out` + `pin`: the caller's three arrays are page-locked from
+        the second call with the same ones on and filled by the device directly (radtran_batch_pin_results_set); this
+        object keeps them alive until spectra_release()."""
         T = np.asfortranarray(T, dtype=np.float64)
         Ts = _c(np.atleast_1d(T_surface))
         if T.ndim != 2 or T.shape[0] != self.nz or T.shape[1] != len(Ts):
             raise ClimaException('"T" has the wrong input dimension.')
         n = T.shape[1]
+        pin = bool(pin) and out is not None
         if out is None:     # (out: three (nz+1, ncol) Fortran-ordered arrays to fill, as a caller that keeps its buffers would)
             out = [np.empty((self.nz + 1, n), order="F") for _ in range(3)]
+        self._L.radtran_batch_pin_results_set(self._ptr, _i(1 if pin else 0))
+        self._locked = getattr(self, "_locked", [])
+        if pin and not any(out is o for o in self._locked):
+            self._locked.append(out)
         self._L.radtran_radiate_ir_batch(self._ptr, _i(n), _d(Ts), _i(T.shape[0]), _i(n), _d(T),
                                          _d(out[0]), _d(out[1]), _d(out[2]), self._err)
         self._check()

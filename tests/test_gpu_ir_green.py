@@ -305,3 +305,30 @@ def test_far_accumulation_on_the_matrix_cores_against_the_vector_kernel(nz, ncol
     for a, b in zip(res[0], res[1]):
         for c in range(ncol):
             assert _scaled(a[:, c], b[:, c]) <= 2.0e-13, (c, _scaled(a[:, c], b[:, c]))
+
+
+def test_batch_results_in_page_locked_caller_arrays(small_tables):
+    """radtran_batch_pin_results_set: from the second call with the same three result arrays on they are page-locked and
+    filled by the device directly; by default the results come through the handle's pinned block in pieces.  Same
+    values either way, bit for bit (the same device arrays are copied), for the response form and the general kernel."""
+    from clima_amd import synthetic as S
+    from clima_amd.radtran import Radtran
+    nz, ncol = 70, 90
+    col = S.modern_earth_column(nz)
+    r = Radtran(small_tables, nz, 2, 0.25)
+    r.radiate(*col.args())
+    Ts, T = _jacobian_batch(col, nz, ncol, np.random.default_rng(5))
+    for mode in (2, 0):
+        r.ir_green = mode
+        ref = r.radiate_ir_batch(Ts, T)
+        out = [np.full((nz + 1, ncol), np.nan, order="F") for _ in range(3)]
+        for rep in range(3):
+            for o in out:
+                o[...] = np.nan
+            got = r.radiate_ir_batch(Ts, T, out=out, pin=True)
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b), (mode, rep)
+        r.spectra_release()
+        again = r.radiate_ir_batch(Ts, T, out=out)        # unpinned again: the same arrays, now pageable
+        for a, b in zip(again, ref):
+            assert np.array_equal(a, b)

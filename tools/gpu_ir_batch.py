@@ -2,13 +2,15 @@
 """Developer diagnostic: the RCE Jacobian's radiative work on AdiabatClimate's doubled radiative grid
 (src/adiabat/clima_adiabat_solve.f90:768-822: nz_r + 1 IR-only calls on unchanged opacities; nz_r = 2 nz + 2,
 src/adiabat/clima_adiabat.f90:729-773) through radtran_radiate_ir_batch, config 2's tables, host arrays in / out.
-Usage: gpu_ir_batch.py [nz ...] (AdiabatClimate nz).  CLIMA_HIP_BATCH_SHARED=0 times the per-column form."""
+Usage: gpu_ir_batch.py [nz ...] (AdiabatClimate nz).  CLIMA_HIP_BATCH_SHARED=0 times the per-column form;
+CLIMA_BATCH_PIN=0 leaves the result arrays pageable (radtran_batch_pin_results_set)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from clima_amd import synthetic as S
 from clima_amd.atmosphere import copy_atm_to_radiative_grid
 from clima_amd.radtran import Radtran
+PIN = os.environ.get("CLIMA_BATCH_PIN", "1") != "0"    # the caller's result arrays page-locked (the default here: a caller that keeps them); 0: through the pinned block
 tb = S.modern_earth_tables()
 for nz in [int(a) for a in sys.argv[1:]] or [50, 100, 200]:
     col = S.Column(copy_atm_to_radiative_grid(S.modern_earth_column(nz)))
@@ -28,7 +30,7 @@ for nz in [int(a) for a in sys.argv[1:]] or [50, 100, 200]:
         best = 1e9
         for rep in range(5):     # (the caller keeps its result arrays, as the Fortran host does)
             t0 = time.time()
-            r.radiate_ir_batch(Ts, T, out=out)
+            r.radiate_ir_batch(Ts, T, out=out, pin=PIN)
             best = min(best, time.time() - t0)
         res[mode] = (best, out, r.ir_green_batches)
     gen, best = res[0][0], res[1][0]
