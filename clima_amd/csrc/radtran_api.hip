@@ -202,6 +202,7 @@ struct Radtran {
   std::vector<std::pair<void *, size_t>> host_registered;   // caller arrays page-locked by radtran_spectra_get_all / radtran_radiate_ir_batch
   double *batch_out[3] = {nullptr, nullptr, nullptr};       // the result arrays of the last radtran_radiate_ir_batch call
   size_t batch_out_n = 0;
+  int batch_shared_min = 2;                                 // CLIMA_HIP_BATCH_SHARED_MIN: batches of at most so many columns take the per-column kernel
   bool batch_pin_results = false;                           // radtran_batch_pin_results_set
   hipEvent_t bout_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the batch's result pieces
   hipStream_t copy_streams[3] = {nullptr, nullptr, nullptr}; // radtran_spectra_get_all: the seven copies go out over four queues
@@ -1343,6 +1344,7 @@ void radtran_create_end(void *ptr, const int *num_zenith_angles, const double *s
   if (const char *f = getenv("CLIMA_HIP_TS_NCOLS")) r->ts_ncols_env = atoi(f);
   if (const char *f = getenv("CLIMA_HIP_BATCH_SHARED")) r->batch_shared = atoi(f) != 0;
   if (const char *f = getenv("CLIMA_HIP_IR_GREEN")) r->ir_green_mode = std::max(0, std::min(2, atoi(f)));
+  if (const char *f = getenv("CLIMA_HIP_BATCH_SHARED_MIN")) r->batch_shared_min = std::max(0, atoi(f));
   if (const char *f = getenv("CLIMA_HIP_FUSED_SPINS")) r->fused_max_spins = std::max(0, atoi(f));  // test aid: 0 makes waits expire
 
   // ---- tables to HBM + interpolation slots
@@ -1521,7 +1523,12 @@ static void ir_batch_general(Radtran *r, const double *d_T, const double *d_Ts, 
     TwoStreamParams tb = ts;
     tb.T = d_T + (size_t)c0 * nz; tb.T_surface = d_Ts + c0; tb.b_ncol = nc;
     // shared-matrix batch kernel (up to 512 layers); otherwise one full solve per column
-    const bool shared_ok = r->batch_shared && launch_twostream_ir_batch(tb, nc, r->stream);
+    // (one or two columns of more than 256 layers -- the response form's base profile and a dense column -- take the
+    // single call's kernel: the 5-8 slot forms of the shared-matrix kernel run one wave per SIMD and amortise their
+    // temperature-independent part over the columns of a block; measured at 402 layers, one column: 26 us less.  At
+    // 202 layers the shared-matrix kernel is the faster one even alone: 20 us.)
+    const bool tiny = nc <= r->batch_shared_min && nz > 256;
+    const bool shared_ok = r->batch_shared && !tiny && launch_twostream_ir_batch(tb, nc, r->stream);
     HIPCHK(hipGetLastError());
     if (!shared_ok) {
       if (split) {  // g-point groups add into zeroed spectra
@@ -1801,9 +1808,18 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   }
   double t_d2h = 0.0;
   if (direct) {
-    for (int i = 0; i < 3; i++)
-      HIPCHK(hipMemcpyAsync(outs[i], r->d_bout.p + (size_t)i * arr, sizeof(double) * arr, hipMemcpyDeviceToHost, r->stream));
-    HIPCHK(hipStreamSynchronize(r->stream));
+    // one array per copy queue (one queue sustains ~41 GB/s of the link, three of them more), behind the kernels by an event
+    for (auto &cs : r->copy_streams)
+      if (!cs) HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    for (auto &e : r->bout_ev)
+      if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipStream_t qs[3] = {r->stream, r->copy_streams[0], r->copy_streams[1]};
+    HIPCHK(hipEventRecord(r->bout_ev[0], r->stream));
+    for (int i = 0; i < 3; i++) {
+      if (i) HIPCHK(hipStreamWaitEvent(qs[i], r->bout_ev[0], 0));
+      HIPCHK(hipMemcpyAsync(outs[i], r->d_bout.p + (size_t)i * arr, sizeof(double) * arr, hipMemcpyDeviceToHost, qs[i]));
+    }
+    for (int i = 0; i < 3; i++) HIPCHK(hipStreamSynchronize(qs[i]));
     t_d2h = times ? since() : 0.0;
   } else {
     constexpr int NPIECE = 6;
