@@ -1554,9 +1554,11 @@ static void ir_batch_general(Radtran *r, const double *d_T, const double *d_Ts, 
 // grid: a few) temperatures changed each; with the opacities fixed the IR solve is linear in the Planck values, so
 // such a column is F(base) + unit responses x Planck differences.  The plan below finds the base (per level the
 // temperature two of three sample columns share) and every column's deviations from it; a column with more than
-// GREEN_MAX_DEV of them (the surface-temperature column of a convective profile moves every layer) goes through the
+// green_max_dev(nz) of them (the surface-temperature column of a convective profile moves every layer) goes through the
 // general kernel together with the base profile itself.
-constexpr int GREEN_MAX_DEV = 8;
+// (8 in round 3.  With the accumulation on the matrix cores a deviation costs ~0.5 us at 402 layers where a column of the
+// general kernel costs 17: the bound grows with the height of the grid, nz / 16 between 8 and 32.)
+static int green_max_dev(int nz) { return std::min(32, std::max(8, nz / 16)); }
 struct GreenPlan {
   std::vector<double> base;              // [nz] ground-first, then the surface temperature
   std::vector<int> dense;                // columns for the general kernel
@@ -1578,13 +1580,14 @@ static void green_plan(const double *T, const double *Ts, int n, int nz, GreenPl
     }
   }
   pl.col_src.assign(n, -1);
+  const int max_dev = green_max_dev(nz);
   std::vector<int> dk, dc; std::vector<double> dT;
   const double *base = pl.base.data();
   for (int c = 0; c < n; c++) {
     const double *Tc = T + (size_t)c * nz;
     int cnt = Ts[c] != base[nz] ? 1 : 0;
     for (int j = 0; j < nz; j++) cnt += Tc[j] != base[j] ? 1 : 0;      // (no early exit: this loop vectorises)
-    if (cnt > GREEN_MAX_DEV) { pl.col_src[c] = 1 + (int)pl.dense.size(); pl.dense.push_back(c); continue; }
+    if (cnt > max_dev) { pl.col_src[c] = 1 + (int)pl.dense.size(); pl.dense.push_back(c); continue; }
     pl.n_sparse++;
     if (cnt == 0) continue;
     for (int j = 0; j <= nz; j++) {
@@ -1759,9 +1762,15 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
     // not with a base that is not a number anywhere (every column would "deviate" there and inherit it), nor when the
     // work arrays (~150 KB per (bin, g-point) at 500 layers) would take more than 16 GB
     for (double v : pl.base) if (!std::isfinite(v)) green = false;
-    // (the partial sums of the two accumulation kernels are part of that: at most (64 + bins) splits x deviations x 2 x levels)
-    if (((double)r->ir_n * r->ng * (13.0 * nl + 14.0 * nz + 4.3 * nl) +
-         (64.0 + r->ir_n) * ((double)pl.dev_k.size() + 64.0) * 2.0 * nl) * 8.0 > 16.0e9) green = false;
+    // (the partial sums of the two accumulation kernels are part of that: their bin splits x deviations x 2 x levels, with
+    // ir_batch_green's split counts -- the mixed blocks' from a lower bound of their number, one per deviation)
+    {
+      const int ndev = (int)pl.dev_k.size();
+      const int qs = green_far_splits(r->ir_n, green_far_waves(ndev, nl));
+      const int ms = std::max(qs, std::min(r->ir_n, 4096 / std::max((ndev + 3) / 4, 1)));
+      if (((double)r->ir_n * r->ng * (13.0 * nl + 14.0 * nz + 4.3 * nl) +
+           (double)(qs + ms) * ((double)ndev + 64.0) * 2.0 * nl) * 8.0 > 16.0e9) green = false;
+    }
     if (!fits) green = false;
     if (green) ir_batch_green(r, pl, T, T_surface, n, r->d_bout.p, pre ? &gpre : nullptr);
     r->green_last_n = green ? n : -1;

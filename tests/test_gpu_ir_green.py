@@ -332,3 +332,44 @@ def test_batch_results_in_page_locked_caller_arrays(small_tables):
         again = r.radiate_ir_batch(Ts, T, out=out)        # unpinned again: the same arrays, now pageable
         for a, b in zip(again, ref):
             assert np.array_equal(a, b)
+
+
+def test_thousands_of_deviations_in_few_bin_splits():
+    """420 columns x 8 changed levels on a 130-layer grid: 3 360 deviations, so many chunks per level block that the far
+    accumulation's waves fill the machine with fewer than 8 bin splits -- its chunks then go round the XCDs instead of
+    its splits (the other mapping idled 6 of 8 XCDs: 5.96 ms where 1.2 are due).  Matrix form against the vector form and
+    both against the general kernel."""
+    import ctypes as C
+    from clima_amd import synthetic as S
+    from clima_amd.lib import load
+    from clima_amd.radtran import Radtran
+    L = load()
+    nz, ncol, per = 130, 420, 8
+    tb = S.modern_earth_tables(nw=40, seed=13)
+    col = S.modern_earth_column(nz)
+    r = Radtran(tb, nz, 2, 0.2)
+    r.radiate(*col.args())
+    rng = np.random.default_rng(99)
+    T = np.repeat(np.asarray(col["T"], dtype=float)[:, None], ncol, axis=1)
+    Ts = np.full(ncol, float(col["T_surface"]))
+    for c in range(ncol):
+        for j in rng.choice(nz + 1, per, replace=False):
+            if j == nz:
+                Ts[c] += rng.uniform(-3, 3)
+            else:
+                T[j, c] += rng.uniform(-3, 3)
+    r.ir_green = 0
+    gen = r.radiate_ir_batch(Ts, T)
+    r.ir_green = 2
+    res = {}
+    try:
+        for form in (1, 0):
+            L.clima_test_green_far_form_set(C.byref(C.c_int(form)))
+            res[form] = r.radiate_ir_batch(Ts, T)
+    finally:
+        L.clima_test_green_far_form_set(C.byref(C.c_int(0)))
+    assert r.ir_green_batches == 2
+    for a, b, g in zip(res[0], res[1], gen):
+        for c in range(ncol):
+            assert _scaled(a[:, c], b[:, c]) <= 2.0e-13, (c, _scaled(a[:, c], b[:, c]))
+            assert _scaled(a[:, c], g[:, c]) <= 1.0e-11, (c, _scaled(a[:, c], g[:, c]))

@@ -35,8 +35,8 @@ say "2a. library host side: hipcc host-only ASan + UBSan build"
 mkdir -p clima_amd/csrc/_san
 RT=$(ls -d /opt/rocm/lib/llvm/lib/clang/*/lib/linux | head -1)
 /opt/rocm/bin/hipcc $SANFLAGS -fno-gpu-sanitize -shared-libasan --offload-arch=gfx950 -std=c++17 -fPIC -shared -w \
-  -mllvm -instcombine-max-copied-from-constant-users=100000 clima_amd/csrc/kernels.hip clima_amd/csrc/radtran_api.hip \
-  -o clima_amd/csrc/_san/libclima_radtran_hip.so -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,$RT 2>&1 | tee -a $LOG || fail "library asan build"
+  -mllvm -instcombine-max-copied-from-constant-users=100000 clima_amd/csrc/kernels.hip clima_amd/csrc/radtran_api.hip clima_amd/csrc/radtran_loader.hip \
+  -o clima_amd/csrc/_san/libclima_radtran_hip.so -L/opt/rocm/lib -lrccl -ldl -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,$RT 2>&1 | tee -a $LOG || fail "library asan build"
 
 say "2b. library host side: C driver (construction, validation and error paths, getters, destruction; leak check on)"
 cat > clima_amd/csrc/_san/lsan.supp <<SUPP
