@@ -3557,6 +3557,10 @@ __global__ __launch_bounds__(256) void k_integrate_partial_b(BatchIntegrateParam
   const int l1 = min(p.ir_lo + p.ir_n, l0 + INT_CHUNK);
   // (the chunk's loads go out together: one after the other, each waiting for the one before, a one-column batch -- the
   // response form's base profile -- spent 18 us here)
+  if (l1 <= l0) {     // a rank without IR bins (a bin shard of solar bins only): its one chunk is empty
+    for (int i = threadIdx.x; i < nl; i += blockDim.x) p.partial[(((size_t)col * 2 + a) * p.nchunk + blockIdx.x) * nl + i] = 0.0;
+    return;
+  }
   for (int i = threadIdx.x; i < nl; i += blockDim.x) {
     double v[INT_CHUNK], df[INT_CHUNK];
 #pragma unroll
