@@ -1817,18 +1817,11 @@ void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surfac
   }
   double t_d2h = 0.0;
   if (direct) {
-    // one array per copy queue (one queue sustains ~41 GB/s of the link, three of them more), behind the kernels by an event
-    for (auto &cs : r->copy_streams)
-      if (!cs) HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    for (auto &e : r->bout_ev)
-      if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipStream_t qs[3] = {r->stream, r->copy_streams[0], r->copy_streams[1]};
-    HIPCHK(hipEventRecord(r->bout_ev[0], r->stream));
-    for (int i = 0; i < 3; i++) {
-      if (i) HIPCHK(hipStreamWaitEvent(qs[i], r->bout_ev[0], 0));
-      HIPCHK(hipMemcpyAsync(outs[i], r->d_bout.p + (size_t)i * arr, sizeof(double) * arr, hipMemcpyDeviceToHost, qs[i]));
-    }
-    for (int i = 0; i < 3; i++) HIPCHK(hipStreamSynchronize(qs[i]));
+    // (one queue: the three arrays over three copy queues behind an event took 86 instead of 95 us at 403 x 403 and
+    // 50-150 us MORE at 201 x 201 -- the extra queues' start-up)
+    for (int i = 0; i < 3; i++)
+      HIPCHK(hipMemcpyAsync(outs[i], r->d_bout.p + (size_t)i * arr, sizeof(double) * arr, hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
     t_d2h = times ? since() : 0.0;
   } else {
     constexpr int NPIECE = 6;
