@@ -3271,6 +3271,11 @@ __global__ __launch_bounds__(OP_THREADS, 2) void k_fused(OpacityParams op, TwoSt
   const int cb = (int)blockIdx.x / per_col, loc = (int)blockIdx.x - cb * per_col;
   if (loc < fp.n_op) {
     // ---- an opacity tile of column cb
+    // The opacity tiles' waves go first where a SIMD holds a wave of either kind (round 4, A/B on one box, three rounds
+    // each: config 2 89.4 against 90.0 us per call, config 3 82.5 against 82.9, config 5 even; priority 3 the same as 1;
+    // the two-stream blocks' waves first instead: 91.2).  The tiles are the kernel's critical path -- every two-stream
+    // block waits for some of them -- and a two-stream wave is latency-bound whichever slot it gets.
+    __builtin_amdgcn_s_setprio(1);
     const size_t oc = (size_t)cb * fp.bs.col;
     if ((long)loc * OP_THREADS < (long)op.nbins * op.col.meta[2 * oc])  // tiles past the compacted lane range are empty
       opacity8_body<RM, CUSTOM, true>(op, loc, oc, (size_t)cb * fp.bs.prep, (size_t)cb * fp.bs.opr);
