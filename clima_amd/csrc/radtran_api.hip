@@ -1621,7 +1621,7 @@ static void green_factor_part(Radtran *r, GreenParams &g) {
   const int NQ = n_ir * ng;
   const size_t RQ = (size_t)N * NQ, LQ = (size_t)nl * NQ;
   const size_t FQ = (size_t)2 * ((nl + 15) / 16) * 34 * NQ;    // (GREEN_LB, GREEN_FS of ir_green.inc)
-  const size_t total = 7 * RQ + 6 * LQ + FQ + 10 * LQ;
+  const size_t total = 7 * RQ + 6 * LQ + FQ + 8 * LQ + 4 * (size_t)NQ;
   if (r->d_green.n < total) r->d_green.alloc(total);
   std::memset(&g, 0, sizeof(g));
   g.nz = nz; g.ng = ng; g.n_ir = n_ir; g.ir_lo = r->ir_lo; g.ir_start = r->ir.ind_start; g.NQ = NQ;
@@ -1631,7 +1631,7 @@ static void green_factor_part(Radtran *r, GreenParams &g) {
   double *w = r->d_green.p;
   auto take = [&](size_t cnt) { double *p0 = w; w += cnt; return p0; };
   g.RW = take(7 * RQ);
-  g.IS = take(6 * LQ); g.FS = take(FQ); g.DS = take(10 * LQ);
+  g.IS = take(6 * LQ); g.FS = take(FQ); g.DS = take(8 * LQ); g.D0 = take(4 * (size_t)NQ);
   launch_green_factor(g, r->stream);
   HIPCHK(hipGetLastError());
 }
@@ -2663,7 +2663,7 @@ void clima_test_ir_response(const int *nz_, const int *ng_, const double *tau, c
   d_wbin.upload(std::vector<double>(wbin, wbin + ng)); d_em.upload(std::vector<double>{ir_par[0]});
   d_db.upload(h_db); d_idx.upload(hi);
   const size_t RQ = (size_t)N * ng, LQ = (size_t)nl * ng, FQ = (size_t)2 * nblk * 34 * ng;
-  d_work.alloc(7 * RQ + 6 * LQ + FQ + 10 * LQ + (size_t)ndev_pad * 2 * nl); d_work.zero();
+  d_work.alloc(7 * RQ + 6 * LQ + FQ + 8 * LQ + 4 * (size_t)ng + (size_t)ndev_pad * 2 * nl); d_work.zero();
   GreenParams gp;
   std::memset(&gp, 0, sizeof(gp));
   gp.nz = nz; gp.ng = ng; gp.n_ir = 1; gp.ir_lo = 0; gp.ir_start = 0; gp.NQ = ng;
@@ -2671,7 +2671,7 @@ void clima_test_ir_response(const int *nz_, const int *ng_, const double *tau, c
   gp.has_hard_surface = ir_par[1] != 0.0 ? 1 : 0; gp.ir_tau_min = ir_par[2];
   double *w = d_work.p;
   auto take = [&](size_t cnt) { double *p0 = w; w += cnt; return p0; };
-  gp.RW = take(7 * RQ); gp.IS = take(6 * LQ); gp.FS = take(FQ); gp.DS = take(10 * LQ);
+  gp.RW = take(7 * RQ); gp.IS = take(6 * LQ); gp.FS = take(FQ); gp.DS = take(8 * LQ); gp.D0 = take(4 * (size_t)ng);
   gp.partial = take((size_t)ndev_pad * 2 * nl);
   gp.DB = d_db.p;
   gp.ndev = ndev; gp.ndev_pad = ndev_pad; gp.qsplit = 1; gp.msplit = 1; gp.partial_m = gp.partial;   // (disjoint pairs: one array)

@@ -296,7 +296,8 @@ struct GreenParams {
   double *RW;                              // [NQ][7][2 nz] per row: c', 1/den, z, running products of phi and of -c' (mantissa, exponent)
   double *IS;                              // [NQ][6][nz+1]: per level, above form (log, up, down) and below form
   double *FS;                              // [NQ][2][blocks of 16 levels][34]: the same relative to a block's reference level
-  double *DS;                              // [NQ][10][nz+1]: per k, amplitudes and logs of the two forms, explicit levels
+  double *DS;                              // [NQ][8][nz+1]: per k, (amplitude, log) pairs of the two forms, explicit values of the levels k, k+1
+  double *D0;                              // [NQ][2][2]: level 0's explicit values (up, down) for k = 0, 1
   // deviations (sorted by k), padded to a multiple of 16
   int ndev, ndev_pad;
   const int *dev_k;
