@@ -32,6 +32,9 @@ fi
 if want profile; then
 # ---- kernel statistics + PMC passes of the default workload
 bash tools/gpu_profile.sh $tag || exit 1
+# ... and of configs 3 and 5 (their bench lines take traffic and issue fraction from the same JSON record)
+PMC_EXTRA="--config 3" bash tools/gpu_profile.sh ${tag}c3 --config 3 --steps 100 --warmup 20 --no-cpu-baseline || exit 1
+PMC_EXTRA="--config 5" bash tools/gpu_profile.sh ${tag}c5 --config 5 --steps 100 --warmup 20 --no-cpu-baseline || exit 1
 fi
 if want sweeps1; then
 # ---- sweeps
