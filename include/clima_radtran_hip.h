@@ -185,7 +185,7 @@ void radtran_toa_fluxes_batch(void *ptr, const int *ncol, const double *T_surfac
  * The results come back through the handle's pinned block, in pieces the host copies out while the next one is on the
  * link.  After radtran_batch_pin_results_set(handle, 1) a caller that passes the same three result arrays as in its
  * previous batch call (the Jacobian's work arrays) has them page-locked from that second call on, like the arrays of
- * radtran_spectra_get_all, and filled by the device directly (402 x 403: 0.79 instead of 0.86 ms): they must then stay
+ * radtran_spectra_get_all, and filled by the device directly (402 x 403: 0.66 instead of 0.80 ms): they must then stay
  * allocated until radtran_spectra_release or the handle's end.  Off by default. */
 void radtran_radiate_ir_batch(void *ptr, const int *ncol, const double *T_surface, const int *dim1_T,
                               const int *dim2_T, const double *T, double *fup_n, double *fdn_n,
