@@ -442,18 +442,26 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams p) {
   const int s = blockIdx.x - 1;
   const SlotDev &sl = p.slots[s];
   const bool in_lds = sl.n <= PREP_AXIS_MAX;
+  // this thread's first layer: its input goes out together with the axis (and, for a layer that is its own source -- all of
+  // them unless the column has reuse pairs -- with the source index itself): one memory round trip where the axis, the
+  // index and the value took three, one behind the other
+  const double *in = sl.source <= 0 ? c.P : sl.source == 1 ? c.T : c.radii + (size_t)(sl.source - 2) * nz;
+  const int j0 = threadIdx.x;
+  int js0 = 0;
+  double x0 = 0.0;
+  if (j0 < nz) { js0 = sl.source < 0 ? j0 : src[j0]; x0 = in[j0]; }
   if (in_lds)
     for (int i = threadIdx.x; i < sl.n; i += blockDim.x) s_axis[i] = sl.axis[i];
   __syncthreads();
   const double *axis = in_lds ? s_axis : sl.axis;
   for (int j = threadIdx.x; j < nz; j += blockDim.x) {
     // custom optical properties are evaluated for every layer itself (types.f90:564-569)
-    const int js = sl.source < 0 ? j : src[j];
+    const int js = j == j0 ? js0 : (sl.source < 0 ? j : src[j]);
+    const double xin = (j == j0 && js == j) ? x0 : in[js];
     double x;
-    if (sl.source < 0) x = log10(c.P[js] * 1.0e6);  // log10P_cgs, types.f90:606
-    else if (sl.source == 0) x = log10(c.P[js]);
-    else if (sl.source == 1) x = c.T[js];
-    else x = c.radii[(sl.source - 2) * nz + js];
+    if (sl.source < 0) x = log10(xin * 1.0e6);  // log10P_cgs, types.f90:606
+    else if (sl.source == 0) x = log10(xin);
+    else x = xin;
     if (sl.flag_clamp && (x < sl.lo || x > sl.hi)) atomicMax(c.err_flag, p.call_id);  // stamped, never reset
     x = fmin(fmax(x, sl.lo), sl.hi);  // :655-656, :910, :937, :974
     const int i = bracket(axis, sl.n, x);
